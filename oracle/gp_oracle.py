@@ -1,0 +1,574 @@
+"""CPU oracle for the dense GP hot path -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+This file restates, in plain NumPy/SciPy, the algorithm of the reference
+(acerbilab/gpyreg) for the one path this repository accelerates.  It exists only
+so that ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg can check (and time) the HIP implementation against it.
+Nothing under ``gpyreg_amd/`` may import it; the product path fails loudly when
+the HIP library is missing.
+
+Parity pin: every function below is checked bit-for-bit / to 1e-12 against
+golden vectors produced by importing the reference itself in the build container
+(``tests/golden/make_golden.py`` -> ``tests/golden/*.npz``,
+``tests/test_oracle_golden.py``).
+
+Reference lines followed (paths relative to the reference checkout):
+  covariance_functions.py:135-186   SquaredExponential.compute
+  covariance_functions.py:221-285   Matern.compute (degrees 1/3/5, :210-218)
+  covariance_functions.py:301-367   RationalQuadraticARD.compute
+  isotropic_covariance_functions.py:104-161, :173-221   isotropic variants
+  noise_functions.py:179-283        GaussianNoise.compute
+  mean_functions.py:82-131, :210-260, :340-397   Zero/Constant/NegativeQuadratic
+  gaussian_process.py:2357-2521     GP.__core_computation
+  gaussian_process.py:1663-1816     GP.predict
+  gaussian_process.py:870-884       GP.update full-recompute loop
+
+Third-party arithmetic the reference delegates to (source not in the reference
+tree): scipy.spatial.distance.{pdist,cdist,squareform}, scipy.linalg.{cholesky,
+solve_triangular}; the oracle calls the very same SciPy entry points so that its
+floating-point results are those of the reference on the same machine.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import scipy.linalg as sla
+from scipy.spatial.distance import cdist, pdist, squareform
+
+# --------------------------------------------------------------------------
+# model descriptors (plain tuples/dicts; no classes so nothing here can be
+# mistaken for the plugin API of the product)
+# --------------------------------------------------------------------------
+
+KERNELS = ("se", "matern", "rq", "se_iso", "matern_iso")
+MEANS = ("zero", "const", "negquad")
+
+
+def cov_count(kernel: str, D: int) -> int:
+    """covariance_functions.py:59-73, :291-292; isotropic_...py:14-28."""
+    if kernel in ("se", "matern"):
+        return D + 1
+    if kernel == "rq":
+        return D + 2
+    if kernel in ("se_iso", "matern_iso"):
+        return 2
+    raise ValueError(kernel)
+
+
+def mean_count(mean: str, D: int) -> int:
+    """mean_functions.py:12-26, :139-154, :268-283."""
+    return {"zero": 0, "const": 1, "negquad": 1 + 2 * D}[mean]
+
+
+def noise_count(params) -> int:
+    """noise_functions.py:43-59.  params = (const, user, rectlin) flags 0/1/2."""
+    n = 0
+    if params[0] == 1:
+        n += 1
+    if params[1] == 2:
+        n += 1
+    if params[2] == 1:
+        n += 2
+    return n
+
+
+def _matern_f_df(degree: int):
+    """covariance_functions.py:210-218."""
+    if degree == 1:
+        return (lambda t: 1), (lambda t: 1 / t)
+    if degree == 3:
+        return (lambda t: 1 + t), (lambda t: 1)
+    if degree == 5:
+        return (lambda t: 1 + t * (1 + t / 3)), (lambda t: (1 + t) / 3)
+    raise ValueError("Only degrees 1, 3 and 5 are supported")
+
+
+# --------------------------------------------------------------------------
+# covariance
+# --------------------------------------------------------------------------
+
+
+def covariance(
+    kernel: str,
+    hyp: np.ndarray,
+    X: np.ndarray,
+    X_star: np.ndarray | None = None,
+    compute_diag: bool = False,
+    compute_grad: bool = False,
+    degree: int = 0,
+):
+    """K (and dK[N,N,cov_N]) exactly as the reference's ``compute`` methods.
+
+    Order of floating-point operations follows the reference line by line
+    (scale X first, then SciPy distance, then the kernel function) because the
+    golden test is bit-exact.
+    """
+    N, D = X.shape
+    cov_N = cov_count(kernel, D)
+    if hyp.size != cov_N:
+        raise ValueError(
+            f"Expected {cov_N} covariance function hyperparameters, "
+            f"{hyp.size} passed instead."
+        )
+    if hyp.ndim != 1:
+        raise ValueError(
+            "Covariance function output is available only for "
+            "one-sample hyperparameter inputs."
+        )
+    if compute_grad and X_star is not None:
+        raise ValueError("X_star should be None when compute_grad is True.")
+
+    iso = kernel.endswith("_iso")
+    if iso:
+        ell = np.exp(hyp[0])  # isotropic_...py:127, :196
+        sf2 = np.exp(2 * hyp[1])
+    else:
+        ell = np.exp(hyp[0:D])  # covariance_functions.py:158, :244, :324
+        sf2 = np.exp(2 * hyp[D])
+
+    if kernel in ("se", "se_iso"):
+        # covariance_functions.py:161-169 / isotropic :199-207
+        if X_star is None:
+            if compute_diag:
+                tmp = np.zeros((N, 1))
+            else:
+                tmp = squareform(pdist(X / ell, "sqeuclidean"))
+        else:
+            tmp = cdist(X / ell, X_star / ell, "sqeuclidean")
+        K = sf2 * np.exp(-tmp / 2)
+        if not compute_grad:
+            return K
+        dK = np.zeros((cov_N, N, N))
+        if iso:
+            dK[0] = K * squareform(pdist(X / ell, "sqeuclidean"))  # :216
+            dK[1] = 2 * K
+        else:
+            for i in range(D):  # :177-181
+                dK[i] = K * squareform(
+                    pdist(np.reshape(X[:, i] / ell[i], (-1, 1)), "sqeuclidean")
+                )
+            dK[D] = 2 * K
+        return K, dK.transpose(1, 2, 0)
+
+    if kernel in ("matern", "matern_iso"):
+        f, df = _matern_f_df(degree)
+        if iso:
+            # isotropic :130-138
+            if X_star is None:
+                if compute_diag:
+                    tmp = np.zeros((N, 1))
+                else:
+                    tmp = squareform(pdist(X * np.sqrt(degree) / ell))
+            else:
+                tmp = cdist(
+                    X * np.sqrt(degree) / ell, X_star * np.sqrt(degree) / ell
+                )
+        else:
+            # covariance_functions.py:247-257
+            S = np.diag(np.sqrt(degree) / ell)
+            if X_star is None:
+                if compute_diag:
+                    tmp = np.zeros((N, 1))
+                else:
+                    tmp = squareform(pdist(X @ S))
+            else:
+                tmp = cdist(X @ S, X_star @ S)
+        K = sf2 * f(tmp) * np.exp(-tmp)
+        if not compute_grad:
+            return K
+        dK = np.zeros((cov_N, N, N))
+        with np.errstate(all="ignore"):
+            if iso:
+                K_ls = squareform(
+                    pdist(np.sqrt(degree) / ell * X, "sqeuclidean")
+                )  # :149-151
+                dK[0] = sf2 * (df(tmp) * np.exp(-tmp)) * K_ls
+                dK[1] = 2 * K
+            else:
+                for i in range(D):  # :267-280
+                    Ki = squareform(
+                        pdist(
+                            np.reshape(np.sqrt(degree) / ell[i] * X[:, i], (-1, 1)),
+                            "sqeuclidean",
+                        )
+                    )
+                    dK[i] = sf2 * (df(tmp) * np.exp(-tmp)) * Ki
+                dK[D] = 2 * K
+        return K, dK.transpose(1, 2, 0)
+
+    if kernel == "rq":
+        alpha = np.exp(hyp[D + 1])  # :326
+        S = np.diag(1.0 / ell)
+        if X_star is None:
+            if compute_diag:
+                tmp = np.zeros((N, 1))
+            else:
+                tmp = squareform(pdist(X @ S, "sqeuclidean"))
+        else:
+            tmp = cdist(X @ S, X_star @ S, "sqeuclidean")
+        M = 1 + 0.5 * tmp / alpha  # :338
+        K = sf2 * M ** (-alpha)
+        if not compute_grad:
+            return K
+        dK = np.zeros((cov_N, N, N))
+        with np.errstate(all="ignore"):
+            for i in range(D):  # :349-357
+                Ki = squareform(
+                    pdist(np.reshape(1.0 / ell[i] * X[:, i], (-1, 1)), "sqeuclidean")
+                )
+                dK[i] = sf2 * M ** (-alpha - 1) * Ki
+        dK[D] = 2 * K
+        dK[D + 1] = K * (0.5 * tmp / M - alpha * np.log(M))  # :363
+        return K, dK.transpose(1, 2, 0)
+
+    raise ValueError(kernel)
+
+
+# --------------------------------------------------------------------------
+# noise and mean (boundary plugins, O(N*D))
+# --------------------------------------------------------------------------
+
+
+def noise(params, hyp, X, y, s2=None, compute_grad=False):
+    """noise_functions.py:227-283.  Returns a Python/NumPy scalar when there is
+    no per-point term, else an (N,1) array -- the distinction drives the branch
+    at gaussian_process.py:2407 / :2491."""
+    N = X.shape[0]
+    noise_N = noise_count(params)
+    if hyp.size != noise_N:
+        raise ValueError(
+            f"Expected {noise_N} noise function hyperparameters, "
+            f"{hyp.size} passed instead."
+        )
+    dsn2 = None
+    if compute_grad:
+        if any(p > 0 for p in params[1:]):
+            dsn2 = np.zeros((N, noise_N))
+        else:
+            dsn2 = np.zeros((1, noise_N))
+    i = 0
+    if params[0] == 0:
+        sn2 = np.spacing(1.0)
+    else:
+        sn2 = np.exp(2 * hyp[i])
+        if compute_grad:
+            dsn2[:, i] = 2 * sn2
+        i += 1
+    if s2 is None:
+        s2 = 0
+    if params[1] == 1:
+        sn2 = sn2 + s2
+    elif params[1] == 2:
+        sn2 = sn2 + np.exp(hyp[i]) * s2
+        if compute_grad:
+            dsn2[:, i : i + 1] = np.exp(hyp[i]) * s2
+        i += 1
+    if params[2] == 1:
+        if y is not None:
+            y_tresh = hyp[i]
+            w2 = np.exp(2 * hyp[i + 1])
+            zz = np.maximum(0, y_tresh - y)
+            sn2 = sn2 + w2 * zz**2
+            if compute_grad:
+                dsn2[:, i : i + 1] = 2 * w2 * (y_tresh - y) * (zz > 0)
+                dsn2[:, i + 1 : i + 2] = 2 * w2 * zz**2
+        i += 2
+    if compute_grad:
+        return sn2, dsn2
+    return sn2
+
+
+def mean(kind: str, hyp, X, compute_grad=False):
+    """mean_functions.py:82-131 (zero), :210-260 (const), :340-397 (negquad)."""
+    N, D = X.shape
+    mean_N = mean_count(kind, D)
+    if hyp.size != mean_N:
+        raise ValueError(
+            f"Expected {mean_N} mean function hyperparameters, "
+            f"{hyp.size} passed instead."
+        )
+    if kind == "zero":
+        m = np.zeros((N,))
+        return (m, []) if compute_grad else m
+    if kind == "const":
+        m = hyp[0] * np.ones((N,))
+        return (m, np.ones((N, 1))) if compute_grad else m
+    m_0 = hyp[0]
+    x_m = hyp[1 : 1 + D]
+    omega = np.exp(hyp[1 + D : 1 + 2 * D])
+    z_2 = ((X - x_m) / omega) ** 2
+    m = m_0 - 0.5 * np.sum(z_2, 1)
+    if compute_grad:
+        dm = np.zeros((N, mean_N))
+        dm[:, 0] = np.ones((N,))
+        dm[:, 1 : D + 1] = (X - x_m) / omega**2
+        dm[:, D + 1 :] = z_2
+        return m, dm
+    return m
+
+
+# --------------------------------------------------------------------------
+# core computation (gaussian_process.py:2357-2521)
+# --------------------------------------------------------------------------
+
+
+class OraclePosterior:
+    """Field-for-field the reference's Posterior record (:2568-2586)."""
+
+    def __init__(self, hyp, alpha, sW, L, sn2_mult, L_chol):
+        self.hyp = hyp
+        self.alpha = alpha
+        self.sW = sW
+        self.L = L
+        self.sn2_mult = sn2_mult
+        self.L_chol = L_chol
+
+
+def core(model, hyp, X, y, s2, compute_nlZ, compute_nlZ_grad):
+    """model = dict(kernel=..., degree=..., mean=..., noise=(c,u,r)).
+
+    Returns nlZ | (nlZ, dnlZ) | OraclePosterior exactly like the reference.
+    """
+    N, d = X.shape
+    kernel, degree = model["kernel"], model.get("degree", 0)
+    cov_N = cov_count(kernel, d)
+    mean_N = mean_count(model["mean"], d)
+    noise_N = noise_count(model["noise"])
+    h_cov = hyp[0:cov_N]
+    h_noise = hyp[cov_N : cov_N + noise_N]
+    h_mean = hyp[cov_N + noise_N : cov_N + noise_N + mean_N]
+
+    if compute_nlZ_grad:
+        sn2, dsn2 = noise(model["noise"], h_noise, X, y, s2, compute_grad=True)
+        m, dm = mean(model["mean"], h_mean, X, compute_grad=True)
+        m = m.reshape((-1, 1))
+        K, dK = covariance(kernel, h_cov, X, compute_grad=True, degree=degree)
+    else:
+        sn2 = noise(model["noise"], h_noise, X, y, s2)
+        m = np.reshape(mean(model["mean"], h_mean, X), (-1, 1))
+        K = covariance(kernel, h_cov, X, degree=degree)
+    sn2_mult = 1
+
+    L_chol = np.min(sn2) >= 1e-6  # :2404
+    L = None
+    if L_chol:
+        if np.isscalar(sn2):
+            sn2_div = sn2
+            sn2_mat = np.eye(N)
+        else:
+            sn2_div = np.min(sn2)
+            sn2_mat = np.diag(sn2.ravel() / sn2_div)
+        for _ in range(10):
+            try:
+                L = sla.cholesky(
+                    K / (sn2_div * sn2_mult) + sn2_mat, check_finite=False
+                )
+            except sla.LinAlgError:
+                sn2_mult *= 10
+                continue
+            break
+        sl = sn2_div * sn2_mult
+        pL = L
+    else:
+        if np.isscalar(sn2):
+            sn2_mat = sn2 * np.eye(N)
+        else:
+            sn2_mat = np.diag(sn2.ravel())
+        for _ in range(10):
+            try:
+                L = sla.cholesky(K + sn2_mult * sn2_mat, check_finite=False)
+            except sla.LinAlgError:
+                sn2_mult *= 10
+                continue
+            break
+        sl = 1
+        if not compute_nlZ:
+            pL = sla.solve_triangular(
+                -L,
+                sla.solve_triangular(L, np.eye(N), trans=1.0, check_finite=False),
+                trans=0,
+                check_finite=False,
+            )
+    if L is None:
+        raise sla.LinAlgError("Singular matrix for L Cholesky decomposition")
+
+    alpha = (
+        sla.solve_triangular(
+            L,
+            sla.solve_triangular(L, y - m, trans=1, check_finite=False),
+            trans=0,
+            check_finite=False,
+        )
+        / sl
+    )
+
+    if compute_nlZ:
+        nlZ = (
+            np.dot((y - m).T, alpha / 2)
+            + np.sum(np.log(np.diag(L)))
+            + N * np.log(2 * np.pi * sl) / 2
+        )
+        if compute_nlZ_grad:
+            dnlZ = np.zeros(hyp.shape)
+            Q = sla.solve_triangular(
+                L,
+                sla.solve_triangular(L, np.eye(N), trans=1, check_finite=False),
+                trans=0,
+                check_finite=False,
+            ) / sl - np.dot(alpha, alpha.T)
+            for i in range(cov_N):
+                dnlZ[i] = np.sum(np.sum(Q * dK[:, :, i])) / 2
+            if np.isscalar(sn2):
+                tr_Q = np.trace(Q)
+                for i in range(noise_N):
+                    dnlZ[cov_N + i] = (0.5 * sn2_mult * np.dot(dsn2[i], tr_Q)).item()
+            else:
+                dg_Q = np.diag(Q)
+                for i in range(noise_N):
+                    dnlZ[cov_N + i] = 0.5 * sn2_mult * np.sum(dsn2[:, i] * dg_Q)
+            if mean_N > 0:
+                dnlZ[cov_N + noise_N :] = np.dot(-dm.T, alpha)[:, 0]
+            return nlZ[0, 0], dnlZ
+        return nlZ[0, 0]
+
+    return OraclePosterior(
+        hyp,
+        alpha,
+        np.ones((N, 1)) / np.sqrt(np.min(sn2) * sn2_mult),
+        pL,
+        sn2_mult,
+        L_chol,
+    )
+
+
+def posteriors(model, hyps, X, y, s2):
+    """GP.update full-recompute loop, gaussian_process.py:870-884."""
+    hyps = np.atleast_2d(hyps)
+    return [core(model, hyps[i], X, y, s2, 0, 0) for i in range(hyps.shape[0])]
+
+
+# --------------------------------------------------------------------------
+# predict (gaussian_process.py:1663-1816)
+# --------------------------------------------------------------------------
+
+
+def predict(
+    model,
+    posts,
+    X,
+    y,
+    x_star,
+    y_star=None,
+    s2_star=None,
+    add_noise=False,
+    separate_samples=False,
+    return_lpd=False,
+):
+    s_N = len(posts)
+    N_star, D = x_star.shape
+    kernel, degree = model["kernel"], model.get("degree", 0)
+    cov_N = cov_count(kernel, D)
+    mean_N = mean_count(model["mean"], D)
+    noise_N = noise_count(model["noise"])
+    mu = np.zeros((N_star, s_N))
+    s2 = np.zeros((N_star, s_N))
+    if return_lpd:
+        if y_star is None:
+            raise ValueError(
+                "Cannot calculate log predictive density without y_star."
+            )
+        if separate_samples:
+            lpd = np.zeros((N_star, s_N))
+    if return_lpd or add_noise:
+        y_s2 = np.zeros((N_star, s_N))
+
+    for s in range(s_N):
+        p = posts[s]
+        hyp, alpha, L, L_chol, sW = p.hyp, p.alpha, p.L, p.L_chol, p.sW
+        m_star = np.reshape(
+            mean(model["mean"], hyp[cov_N + noise_N : cov_N + noise_N + mean_N], x_star),
+            (-1, 1),
+        )
+        kss = covariance(kernel, hyp[0:cov_N], x_star, compute_diag=True, degree=degree)
+        if y is not None:
+            Ks = covariance(kernel, hyp[0:cov_N], X, x_star, degree=degree)
+            mu[:, s : s + 1] = m_star + np.dot(Ks.T, alpha)
+            if L_chol:
+                V = sla.solve_triangular(
+                    L, np.tile(sW, (1, N_star)) * Ks, trans=1, check_finite=False
+                )
+                s2[:, s : s + 1] = kss - np.reshape(np.sum(V * V, 0), (-1, 1))
+            else:
+                s2[:, s : s + 1] = kss + np.reshape(
+                    np.sum(Ks * np.dot(L, Ks), 0), (-1, 1)
+                )
+        else:
+            mu[:, s : s + 1] = m_star
+            s2[:, s : s + 1] = kss
+        s2[:, s] = np.maximum(s2[:, s], 0)
+        if return_lpd or add_noise:
+            sn2_mult = p.sn2_mult if p.sn2_mult is not None else 1
+            sn2_star = noise(
+                model["noise"], hyp[cov_N : cov_N + noise_N], x_star, y_star, s2_star
+            )
+            y_s2[:, s : s + 1] = s2[:, s : s + 1] + sn2_star * sn2_mult
+        if return_lpd and separate_samples:
+            lpd[:, s : s + 1] = -0.5 * (y_star - mu[:, s : s + 1]) ** 2 / y_s2[
+                :, s : s + 1
+            ] - 0.5 * np.log(2 * np.pi * y_s2[:, s : s + 1])
+
+    if add_noise:
+        s2 = y_s2
+    if not separate_samples:
+        if s_N > 1:
+            mu_bar = np.reshape(np.sum(mu, 1), (-1, 1)) / s_N
+            v = np.sum((mu - mu_bar) ** 2, 1) / (s_N - 1)
+            s2 = np.reshape(np.sum(s2, 1) / s_N + v, (-1, 1))
+            mu = mu_bar
+        else:
+            v = 0
+        if return_lpd and add_noise:
+            lpd = -0.5 * (y_star - mu) ** 2 / s2 - 0.5 * np.log(2 * np.pi * s2)
+        elif return_lpd:
+            y_s2 = np.reshape(np.sum(y_s2, 1) / s_N + v, (-1, 1))
+            lpd = -0.5 * (y_star - mu) ** 2 / y_s2 - 0.5 * np.log(2 * np.pi * y_s2)
+    if return_lpd:
+        return mu, s2, lpd
+    return mu, s2
+
+
+# --------------------------------------------------------------------------
+# the synthetic workload of SURVEY.md section 8(d) / BASELINE.md section 3
+# --------------------------------------------------------------------------
+
+BENCH_CONFIGS = {
+    2: dict(N=2048, D=5, kernel="se", degree=0, S=1),
+    3: dict(N=4096, D=10, kernel="matern", degree=5, S=16),
+    4: dict(N=16384, D=20, kernel="rq", degree=0, S=1),
+    5: dict(N=8192, D=8, kernel="se", degree=0, S=64),
+}
+
+
+def synthetic_problem(cfg_idx: int, N=None, D=None, kernel=None, degree=None, S=None):
+    """Seeded synthetic inputs: draw order X, noise for y, then hyp."""
+    c = dict(BENCH_CONFIGS.get(cfg_idx, BENCH_CONFIGS[3]))
+    for k, v in dict(N=N, D=D, kernel=kernel, degree=degree, S=S).items():
+        if v is not None:
+            c[k] = v
+    N, D, S = c["N"], c["D"], c["S"]
+    rng = np.random.default_rng(1000 + cfg_idx)
+    X = rng.uniform(-3, 3, (N, D))
+    y = np.sin(np.sum(X, 1, keepdims=True) / np.sqrt(D)) + 0.1 * rng.standard_normal(
+        (N, 1)
+    )
+    base = [np.log(1.5 * np.sqrt(D) * (1 + 0.1 * d / D)) for d in range(D)]
+    base.append(0.0)  # log sigma_f
+    if c["kernel"] == "rq":
+        base.append(0.0)  # log alpha
+    if c["kernel"].endswith("_iso"):
+        base = [np.log(1.5 * np.sqrt(D)), 0.0]
+    base += [np.log(0.1), 0.0]  # noise, mean
+    base = np.asarray(base)
+    hyp = base + 0.1 * rng.standard_normal((S, base.size))
+    model = dict(kernel=c["kernel"], degree=c["degree"], mean="const", noise=(1, 0, 0))
+    return model, X, y, hyp

@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE itself (build container only).
+
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg \
+        PYTHONPATH=/root/reference python3 /root/repo/tests/golden/make_golden.py
+
+The reference cannot travel to the GPU box, so its outputs are committed here as
+data (inputs + expected outputs only).  Every case is seeded; re-running this
+script reproduces the files bit-for-bit on the same numpy/scipy/OpenBLAS.
+
+Files written next to this script:
+  cov_cases.npz    covariance.compute(): K, dK, K(X,X*), diag for every kernel
+  core_cases.npz   GP.__compute_nlZ (nlZ, dnlZ), Posterior fields, GP.predict
+"""
+
+import os
+import sys
+
+import numpy as np
+
+import gpyreg as gpr  # the reference (PYTHONPATH=/root/reference)
+
+assert "/root/reference" in os.path.abspath(gpr.__file__), gpr.__file__
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+KERNELS = {
+    "se": lambda: gpr.covariance_functions.SquaredExponential(),
+    "matern1": lambda: gpr.covariance_functions.Matern(1),
+    "matern3": lambda: gpr.covariance_functions.Matern(3),
+    "matern5": lambda: gpr.covariance_functions.Matern(5),
+    "rq": lambda: gpr.covariance_functions.RationalQuadraticARD(),
+    "se_iso": lambda: gpr.isotropic_covariance_functions.SquaredExponentialIsotropic(),
+    "matern_iso1": lambda: gpr.isotropic_covariance_functions.MaternIsotropic(1),
+    "matern_iso3": lambda: gpr.isotropic_covariance_functions.MaternIsotropic(3),
+    "matern_iso5": lambda: gpr.isotropic_covariance_functions.MaternIsotropic(5),
+}
+MEANS = {
+    "zero": lambda: gpr.mean_functions.ZeroMean(),
+    "const": lambda: gpr.mean_functions.ConstantMean(),
+    "negquad": lambda: gpr.mean_functions.NegativeQuadratic(),
+}
+
+
+def make_noise(p):
+    return gpr.noise_functions.GaussianNoise(
+        constant_add=p[0] == 1,
+        user_provided_add=p[1] >= 1,
+        scale_user_provided=p[1] == 2,
+        rectified_linear_output_dependent_add=p[2] == 1,
+    )
+
+
+def cov_cases():
+    out = {}
+    names = []
+    idx = 0
+    for kname, mk in KERNELS.items():
+        for (N, D, M) in [(7, 1, 3), (33, 3, 5), (20, 2, 130)]:
+            rng = np.random.default_rng(7000 + idx)
+            cov = mk()
+            cov_N = cov.hyperparameter_count(D)
+            X = rng.uniform(-2, 2, (N, D))
+            Xs = rng.uniform(-2.5, 2.5, (M, D))
+            hyp = 0.5 * rng.standard_normal(cov_N)
+            K, dK = cov.compute(hyp, X, compute_grad=True)
+            Ks = cov.compute(hyp, X, Xs)
+            kd = cov.compute(hyp, Xs, compute_diag=True)
+            tag = f"c{idx:03d}"
+            names.append(f"{tag}|{kname}|{N}|{D}|{M}")
+            out[tag + "_X"] = X
+            out[tag + "_Xs"] = Xs
+            out[tag + "_hyp"] = hyp
+            out[tag + "_K"] = K
+            out[tag + "_dK"] = np.ascontiguousarray(dK)
+            out[tag + "_Ks"] = Ks
+            out[tag + "_kd"] = kd
+            idx += 1
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "cov_cases.npz"), **out)
+    print("cov cases:", len(names))
+
+
+# (kernel, mean, noise params, N, D, flavour)
+CORE_CASES = [
+    ("se", "const", (1, 0, 0), 7, 1, "plain"),
+    ("se", "const", (1, 0, 0), 33, 2, "plain"),
+    ("se", "const", (1, 0, 0), 130, 3, "plain"),
+    ("se", "const", (1, 0, 0), 257, 5, "plain"),
+    ("se", "zero", (1, 0, 0), 33, 2, "plain"),
+    ("se", "negquad", (1, 0, 0), 33, 2, "plain"),
+    ("se", "negquad", (1, 1, 0), 130, 3, "plain"),
+    ("se", "const", (0, 0, 0), 33, 2, "lownoise"),
+    ("se", "const", (0, 0, 0), 130, 2, "lownoise"),
+    ("se", "zero", (0, 1, 0), 33, 2, "plain"),
+    ("se", "const", (1, 1, 0), 33, 2, "plain"),
+    ("se", "const", (1, 2, 0), 33, 2, "plain"),
+    ("se", "const", (1, 0, 1), 33, 2, "plain"),
+    ("se", "negquad", (1, 2, 1), 130, 3, "plain"),
+    ("se", "const", (0, 1, 0), 33, 2, "tiny_s2"),
+    ("matern1", "const", (1, 0, 0), 33, 2, "plain"),
+    ("matern3", "const", (1, 0, 0), 33, 2, "plain"),
+    ("matern3", "negquad", (1, 1, 0), 130, 4, "plain"),
+    ("matern5", "const", (1, 0, 0), 33, 2, "plain"),
+    ("matern5", "const", (1, 0, 0), 257, 10, "plain"),
+    ("matern5", "zero", (0, 0, 0), 33, 3, "lownoise"),
+    ("rq", "const", (1, 0, 0), 33, 2, "plain"),
+    ("rq", "negquad", (1, 2, 0), 130, 3, "plain"),
+    ("rq", "const", (1, 0, 0), 257, 6, "plain"),
+    ("se_iso", "const", (1, 0, 0), 33, 3, "plain"),
+    ("se_iso", "const", (1, 1, 0), 130, 3, "plain"),
+    ("matern_iso1", "const", (1, 0, 0), 33, 2, "plain"),
+    ("matern_iso3", "const", (1, 0, 0), 33, 3, "plain"),
+    ("matern_iso5", "negquad", (1, 0, 0), 130, 3, "plain"),
+    ("se", "const", (1, 0, 0), 33, 2, "jitter_high"),
+    ("se", "const", (0, 0, 0), 33, 2, "jitter_low"),
+    ("matern5", "const", (1, 0, 0), 130, 2, "jitter_high"),
+    ("se", "const", (1, 0, 0), 128, 2, "plain"),
+    ("se", "const", (1, 0, 0), 129, 2, "plain"),
+    ("matern5", "const", (1, 0, 0), 384, 4, "plain"),
+]
+
+
+def core_cases():
+    out = {}
+    names = []
+    for idx, (kname, mname, npar, N, D, flavour) in enumerate(CORE_CASES):
+        rng = np.random.default_rng(9000 + idx)
+        cov, mean, noise = KERNELS[kname](), MEANS[mname](), make_noise(npar)
+        gp = gpr.GP(D=D, covariance=cov, mean=mean, noise=noise)
+        cov_N = cov.hyperparameter_count(D)
+        mean_N = mean.hyperparameter_count(D)
+        noise_N = noise.hyperparameter_count()
+        S = 2
+        X = rng.uniform(-3, 3, (N, D))
+        y = np.sin(np.sum(X, 1, keepdims=True) / np.sqrt(D)) + 0.1 * rng.standard_normal((N, 1))
+        s2 = None
+        if npar[1] >= 1:
+            s2 = 0.01 + 0.05 * rng.uniform(size=(N, 1))
+            if flavour == "tiny_s2":
+                s2 = 1e-8 * (1 + rng.uniform(size=(N, 1)))  # vector noise, L_chol False
+        hyp = np.zeros((S, cov_N + noise_N + mean_N))
+        for s in range(S):
+            h_cov = 0.3 * rng.standard_normal(cov_N)
+            if not kname.endswith(("iso", "iso1", "iso3", "iso5")):
+                h_cov[:D] += np.log(1.2 * np.sqrt(D))
+            else:
+                h_cov[0] += np.log(1.2 * np.sqrt(D))
+            h_noise = []
+            if npar[0] == 1:
+                h_noise.append(np.log(0.1) + 0.2 * rng.standard_normal())
+            if npar[1] == 2:
+                h_noise.append(0.3 * rng.standard_normal())
+            if npar[2] == 1:
+                h_noise += [0.2 * rng.standard_normal(), np.log(0.05) + 0.1 * rng.standard_normal()]
+            if mname == "zero":
+                h_mean = []
+            elif mname == "const":
+                h_mean = [0.2 * rng.standard_normal()]
+            else:
+                h_mean = (
+                    [0.2 * rng.standard_normal()]
+                    + list(0.5 * rng.standard_normal(D))
+                    + list(np.log(4.0) + 0.2 * rng.standard_normal(D))
+                )
+            hyp[s] = np.concatenate([h_cov, h_noise, h_mean])
+        if flavour.startswith("jitter"):
+            # duplicate points + huge output scale -> Cholesky needs the x10 escalation
+            X[N // 2 :] = X[: N - N // 2]
+            if flavour == "jitter_high":
+                hyp[:, D] = 12.0  # log sigma_f
+                hyp[:, cov_N] = np.log(1.1e-3)  # sn2 ~ 1.2e-6 >= 1e-6 -> L_chol True
+            else:
+                hyp[:, D] = 3.0
+        gp.update(X_new=X, y_new=y, s2_new=s2, hyp=hyp)
+        tag = f"g{idx:03d}"
+        names.append(f"{tag}|{kname}|{mname}|{npar[0]}{npar[1]}{npar[2]}|{N}|{D}|{flavour}")
+        out[tag + "_X"] = X
+        out[tag + "_y"] = y
+        if s2 is not None:
+            out[tag + "_s2"] = s2
+        out[tag + "_hyp"] = hyp
+        nlZ = np.zeros(S)
+        dnlZ = np.zeros((S, hyp.shape[1]))
+        nlZ_only = np.zeros(S)
+        for s in range(S):
+            nlZ[s], dnlZ[s] = gp._GP__compute_nlZ(hyp[s], True, False)
+            nlZ_only[s] = gp._GP__compute_nlZ(hyp[s], False, False)
+        out[tag + "_nlZ"] = nlZ
+        out[tag + "_nlZ_only"] = nlZ_only
+        out[tag + "_dnlZ"] = dnlZ
+        out[tag + "_alpha"] = np.stack([p.alpha[:, 0] for p in gp.posteriors])
+        out[tag + "_sW"] = np.stack([p.sW[:, 0] for p in gp.posteriors])
+        out[tag + "_sn2_mult"] = np.array([float(p.sn2_mult) for p in gp.posteriors])
+        out[tag + "_L_chol"] = np.array([bool(p.L_chol) for p in gp.posteriors])
+        if N <= 40:
+            out[tag + "_L"] = np.stack([np.asarray(p.L) for p in gp.posteriors])
+        else:  # keep the fixture small: diagonal, first/last rows, Frobenius norm
+            out[tag + "_Ldiag"] = np.stack([np.diag(p.L) for p in gp.posteriors])
+            out[tag + "_Lrow0"] = np.stack([np.asarray(p.L)[0] for p in gp.posteriors])
+            out[tag + "_Lcol_last"] = np.stack([np.asarray(p.L)[:, -1] for p in gp.posteriors])
+            out[tag + "_Lfro"] = np.array([np.linalg.norm(p.L) for p in gp.posteriors])
+        # predictions
+        M = 11
+        xs = rng.uniform(-3.5, 3.5, (M, D))
+        ys = np.sin(np.sum(xs, 1, keepdims=True) / np.sqrt(D))
+        s2s = 0.02 * np.ones((M, 1)) if s2 is not None else None
+        out[tag + "_xs"] = xs
+        out[tag + "_ys"] = ys
+        mu_sep, s2_sep = gp.predict(xs, ys, s2s, add_noise=False, separate_samples=True)
+        out[tag + "_mu_sep"], out[tag + "_s2_sep"] = mu_sep, s2_sep
+        mu_a, s2_a, lpd_a = gp.predict(xs, ys, s2s, add_noise=True, return_lpd=True)
+        out[tag + "_mu_avg"], out[tag + "_s2n_avg"], out[tag + "_lpd_avg"] = mu_a, s2_a, lpd_a
+        mu_b, s2_b, lpd_b = gp.predict(
+            xs, ys, s2s, add_noise=False, separate_samples=True, return_lpd=True
+        )
+        out[tag + "_lpd_sep"] = lpd_b
+        print(
+            names[-1],
+            "nlZ", nlZ,
+            "mult", out[tag + "_sn2_mult"],
+            "Lchol", out[tag + "_L_chol"],
+            "nan-grad", int(np.isnan(dnlZ).sum()),
+        )
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "core_cases.npz"), **out)
+    print("core cases:", len(names))
+
+
+if __name__ == "__main__":
+    cov_cases()
+    core_cases()
+    sys.exit(0)

@@ -1,0 +1,89 @@
+"""Pins the CPU oracle (oracle/gp_oracle.py) to golden vectors produced by the
+reference itself (tests/golden/make_golden.py).  CPU only.
+
+The oracle calls the same SciPy/NumPy entry points in the same order as the
+reference, so the comparison is bit-exact (``np.array_equal`` with NaNs equal).
+"""
+
+import numpy as np
+import pytest
+
+from conftest import parse_core_name, parse_cov_name
+from oracle import gp_oracle as orc
+
+
+def _eq(a, b):
+    return np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+
+
+def test_cov_golden_bit_exact(cov_golden):
+    g = cov_golden
+    assert len(g["names"]) == 27
+    for name in g["names"]:
+        tag, kernel, degree, N, D, M = parse_cov_name(name)
+        X, Xs, hyp = g[tag + "_X"], g[tag + "_Xs"], g[tag + "_hyp"]
+        K, dK = orc.covariance(kernel, hyp, X, compute_grad=True, degree=degree)
+        assert _eq(K, g[tag + "_K"]), name
+        assert _eq(dK, g[tag + "_dK"]), name
+        assert _eq(orc.covariance(kernel, hyp, X, Xs, degree=degree), g[tag + "_Ks"]), name
+        assert _eq(
+            orc.covariance(kernel, hyp, Xs, compute_diag=True, degree=degree), g[tag + "_kd"]
+        ), name
+
+
+def test_core_golden_bit_exact(core_golden):
+    g = core_golden
+    assert len(g["names"]) == 35
+    for name in g["names"]:
+        tag, model, N, D, flavour = parse_core_name(name)
+        X, y, hyp = g[tag + "_X"], g[tag + "_y"], g[tag + "_hyp"]
+        s2 = g[tag + "_s2"] if tag + "_s2" in g.files else None
+        for s in range(hyp.shape[0]):
+            nlZ, dnlZ = orc.core(model, hyp[s], X, y, s2, 1, 1)
+            assert _eq(nlZ, g[tag + "_nlZ"][s]), name
+            assert _eq(dnlZ, g[tag + "_dnlZ"][s]), name
+            assert _eq(orc.core(model, hyp[s], X, y, s2, 1, 0), g[tag + "_nlZ_only"][s]), name
+        posts = orc.posteriors(model, hyp, X, y, s2)
+        for s, p in enumerate(posts):
+            assert _eq(p.alpha[:, 0], g[tag + "_alpha"][s]), name
+            assert _eq(p.sW[:, 0], g[tag + "_sW"][s]), name
+            assert float(p.sn2_mult) == g[tag + "_sn2_mult"][s], name
+            assert bool(p.L_chol) == bool(g[tag + "_L_chol"][s]), name
+            if tag + "_L" in g.files:
+                assert _eq(p.L, g[tag + "_L"][s]), name
+            else:
+                assert _eq(np.diag(p.L), g[tag + "_Ldiag"][s]), name
+                assert _eq(np.asarray(p.L)[0], g[tag + "_Lrow0"][s]), name
+                assert _eq(np.asarray(p.L)[:, -1], g[tag + "_Lcol_last"][s]), name
+        xs, ys = g[tag + "_xs"], g[tag + "_ys"]
+        s2s = 0.02 * np.ones((xs.shape[0], 1)) if s2 is not None else None
+        mu, v = orc.predict(model, posts, X, y, xs, ys, s2s, separate_samples=True)
+        assert _eq(mu, g[tag + "_mu_sep"]) and _eq(v, g[tag + "_s2_sep"]), name
+        mu, v, lpd = orc.predict(model, posts, X, y, xs, ys, s2s, add_noise=True, return_lpd=True)
+        assert _eq(mu, g[tag + "_mu_avg"]) and _eq(v, g[tag + "_s2n_avg"]), name
+        assert _eq(lpd, g[tag + "_lpd_avg"]), name
+        _, _, lpd = orc.predict(
+            model, posts, X, y, xs, ys, s2s, separate_samples=True, return_lpd=True
+        )
+        assert _eq(lpd, g[tag + "_lpd_sep"]), name
+
+
+def test_golden_covers_edge_semantics(core_golden):
+    """The fixtures really contain the edge cases SURVEY section 8a lists."""
+    g = core_golden
+    names = [str(n) for n in g["names"]]
+    # jitter escalation observed in the reference
+    assert any(g[n.split("|")[0] + "_sn2_mult"].max() > 1 for n in names)
+    # low-noise branch (L_chol False)
+    assert any(not g[n.split("|")[0] + "_L_chol"].all() for n in names)
+    # Matern-1 NaN lengthscale gradients, finite elsewhere
+    tag = [n for n in names if "|matern1|" in n][0].split("|")[0]
+    d = g[tag + "_dnlZ"]
+    assert np.isnan(d[:, :2]).all() and np.isfinite(d[:, 2:]).all()
+
+
+def test_synthetic_problem_matches_survey_value():
+    """reference nlZ(s=0) for cfg2 is -1166.298896135079."""
+    model, X, y, hyp = orc.synthetic_problem(2)
+    nlZ = orc.core(model, hyp[0], X, y, None, 1, 0)
+    assert abs(nlZ - (-1166.298896135079)) < 1e-6 * 1166
