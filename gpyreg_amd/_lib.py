@@ -1,0 +1,288 @@
+"""ctypes binding of libgpcore.so (C ABI in include/gpcore.h).
+
+There is NO CPU fallback: if the shared library is missing, or no HIP device is
+visible, every compute entry point raises ``RuntimeError``.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgpcore.so")
+
+K_SE, K_MATERN, K_RQ, K_SE_ISO, K_MATERN_ISO = range(5)
+F64, F32 = 0, 1
+KLO_ZERO, KLO_ROW, KLO_COL = 0, 1, 2
+KHI_FULL, KHI_ROW, KHI_COL = 0, 1, 2
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_vp = C.c_void_p
+
+# every symbol include/gpcore.h declares: (restype, argtypes)
+SIGNATURES = {
+    "gpc_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "gpc_destroy": (None, [_vp]),
+    "gpc_last_error": (C.c_char_p, [_vp]),
+    "gpc_device_info": (C.c_char_p, [_vp]),
+    "gpc_set_data": (C.c_int, [_vp, _dp, _dp, C.c_int, C.c_int]),
+    "gpc_cov_count": (C.c_int, [C.c_int, C.c_int]),
+    "gpc_kernel": (
+        C.c_int,
+        [_vp, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, _dp, C.c_int, C.c_int, _dp, _dp],
+    ),
+    "gpc_nll_batch": (
+        C.c_int,
+        [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, C.c_int, _dp, C.c_int,
+         _dp, C.c_int, _dp, _dp, _dp, _ip, _ip],
+    ),
+    "gpc_posterior_batch": (
+        C.c_int,
+        [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, C.POINTER(_vp), _dp, _ip, _ip],
+    ),
+    "gpc_post_fetch": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
+    "gpc_post_free": (C.c_int, [_vp]),
+    "gpc_predict": (C.c_int, [_vp, _dp, C.c_int, _dp, _dp]),
+    "gpc_last_timing": (C.c_int, [_vp, _dp, _dp]),
+    "gpc_mfma_peak": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
+    "gpc_debug_gemm": (
+        C.c_int,
+        [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
+         C.c_int, C.c_int, _dp, _dp, _dp],
+    ),
+    "gpc_debug_leaf": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp, _ip]),
+    "gpc_debug_factor": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """Load libgpcore.so and attach prototypes.  Raises RuntimeError when missing."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise RuntimeError(
+                    f"{LIB_PATH} is missing: the HIP extension has not been built "
+                    "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
+                    "gpyreg_amd has no CPU fallback."
+                )
+            lib = C.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)  # AttributeError if the .so does not export it
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+class Context:
+    """One gpc_ctx (device stream + workspace + resident X, y)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load()
+        h = _vp()
+        rc = self._lib.gpc_create(int(device), C.byref(h))
+        if rc != 0:
+            msg = self._lib.gpc_last_error(None).decode()
+            raise RuntimeError(f"gpc_create(device={device}) failed: {msg} (no CPU fallback)")
+        self._h = h
+        self.device = int(device)
+        self.data_token = None
+        self.N = self.D = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.gpc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed (rc={rc}): {self._lib.gpc_last_error(self._h).decode()}")
+
+    def device_info(self) -> str:
+        return self._lib.gpc_device_info(self._h).decode()
+
+    # ---- data -----------------------------------------------------------------
+    def set_data(self, X, y, token=None):
+        X = _f64(X)
+        y = _f64(y).ravel()
+        N, D = X.shape
+        self._check(self._lib.gpc_set_data(self._h, _ptr(X), _ptr(y), N, D), "gpc_set_data")
+        self.N, self.D = N, D
+        self.data_token = token
+
+    # ---- covariance.compute ---------------------------------------------------
+    def kernel(self, kid, degree, hyp, X, X_star=None, diag=False, grad=False):
+        X = _f64(X)
+        hyp = _f64(hyp)
+        N, D = X.shape
+        cov_N = self._lib.gpc_cov_count(kid, D)
+        Xs = None if X_star is None else _f64(X_star)
+        M = 0 if Xs is None else Xs.shape[0]
+        if diag:
+            K = np.empty((N, 1))
+        else:
+            K = np.empty((N, M if Xs is not None else N))
+        dK = np.empty((N, N, cov_N)) if grad else None
+        rc = self._lib.gpc_kernel(self._h, kid, degree, _ptr(hyp), _ptr(X), N, D, _ptr(Xs), M,
+                                  1 if diag else 0, _ptr(K), _ptr(dK))
+        self._check(rc, "gpc_kernel")
+        return (K, dK) if grad else K
+
+    # ---- core -----------------------------------------------------------------
+    def nll_batch(self, kid, degree, dtype, hyp_cov, m, sn2, sn2_is_vector, want_grad=False,
+                  dm=None, dsn2=None):
+        """hyp_cov (S,cov_N); m (S,N); sn2 (S,N) if sn2_is_vector else (S,1);
+        dm (S,N,mean_N); dsn2 (S, N if sn2_is_vector else 1, noise_N)."""
+        hyp_cov = _f64(hyp_cov)
+        m = _f64(m)
+        sn2 = _f64(sn2)
+        S, cov_N = hyp_cov.shape
+        vec = 1 if sn2_is_vector else 0
+        if sn2.shape != (S, self.N if vec else 1) or m.shape != (S, self.N):
+            raise ValueError("m must be (S,N); sn2 must be (S,N) when per-point, else (S,1)")
+        mean_N = 0 if dm is None else dm.shape[2]
+        noise_N = 0 if dsn2 is None else dsn2.shape[2]
+        dm_c = None if dm is None or mean_N == 0 else _f64(dm)
+        dsn2_c = None if dsn2 is None or noise_N == 0 else _f64(dsn2)
+        hyp_N = cov_N + noise_N + mean_N
+        nlz = np.empty(S)
+        dnlz = np.empty((S, hyp_N)) if want_grad else None
+        mult = np.empty(S)
+        lchol = np.empty(S, dtype=np.int32)
+        info = np.empty(S, dtype=np.int32)
+        rc = self._lib.gpc_nll_batch(
+            self._h, kid, degree, dtype, S, _ptr(hyp_cov), _ptr(m), _ptr(sn2), vec,
+            1 if want_grad else 0, _ptr(dm_c), mean_N, _ptr(dsn2_c), noise_N, _ptr(nlz), _ptr(dnlz),
+            _ptr(mult), lchol.ctypes.data_as(_ip), info.ctypes.data_as(_ip))
+        self._check(rc, "gpc_nll_batch")
+        return nlz, dnlz, mult, lchol.astype(bool), info
+
+    def posterior_batch(self, kid, degree, dtype, hyp_cov, m, sn2, sn2_is_vector):
+        hyp_cov = _f64(hyp_cov)
+        m = _f64(m)
+        sn2 = _f64(sn2)
+        S = hyp_cov.shape[0]
+        vec = 1 if sn2_is_vector else 0
+        if sn2.shape != (S, self.N if vec else 1) or m.shape != (S, self.N):
+            raise ValueError("m must be (S,N); sn2 must be (S,N) when per-point, else (S,1)")
+        mult = np.empty(S)
+        lchol = np.empty(S, dtype=np.int32)
+        info = np.empty(S, dtype=np.int32)
+        h = _vp()
+        rc = self._lib.gpc_posterior_batch(
+            self._h, kid, degree, dtype, S, _ptr(hyp_cov), _ptr(m), _ptr(sn2), vec, C.byref(h),
+            _ptr(mult), lchol.ctypes.data_as(_ip), info.ctypes.data_as(_ip))
+        self._check(rc, "gpc_posterior_batch")
+        return PostHandle(self, h, S, self.N), mult, lchol.astype(bool), info
+
+    def last_timing(self):
+        a, b = C.c_double(), C.c_double()
+        self._lib.gpc_last_timing(self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def mfma_peak(self, dtype=F64):
+        """(TFLOP/s, shader cycles per MFMA per SIMD, clock in GHz) of a bare MFMA loop."""
+        t, cyc, ghz = C.c_double(), C.c_double(), C.c_double()
+        rc = self._lib.gpc_mfma_peak(self._h, dtype, C.byref(t), C.byref(cyc), C.byref(ghz))
+        self._check(rc, "gpc_mfma_peak")
+        return t.value, cyc.value, ghz.value
+
+    # ---- test hooks -------------------------------------------------------------
+    def debug_gemm(self, A, B, Cm, M, N, K, a_kmajor, b_kmajor, alpha=1.0, beta=0, klo=0, khi=0,
+                   lower_only=False, dtype=F64):
+        A, B = _f64(A), _f64(B)
+        Cm = _f64(Cm).copy()
+        rc = self._lib.gpc_debug_gemm(self._h, dtype, M, N, K, int(a_kmajor), int(b_kmajor),
+                                      float(alpha), int(beta), klo, khi, int(lower_only), _ptr(A),
+                                      _ptr(B), _ptr(Cm))
+        self._check(rc, "gpc_debug_gemm")
+        return Cm
+
+    def debug_factor(self, A, want_inv=True, dtype=F64):
+        A = _f64(A)
+        n = A.shape[0]
+        L, W = np.empty((n, n)), np.empty((n, n))
+        Ainv = np.empty((n, n)) if want_inv else None
+        logdet = C.c_double()
+        info = C.c_int()
+        rc = self._lib.gpc_debug_factor(self._h, dtype, n, _ptr(A), _ptr(L), _ptr(W), _ptr(Ainv),
+                                        C.byref(logdet), C.byref(info))
+        self._check(rc, "gpc_debug_factor")
+        return L, W, Ainv, logdet.value, info.value
+
+
+class PostHandle:
+    """Device-resident posteriors of one hyperparameter batch (gpc_post)."""
+
+    def __init__(self, ctx: Context, h, S: int, N: int):
+        self.ctx, self._h, self.S, self.N = ctx, h, S, N
+
+    def fetch(self, s, alpha=True, sW=True, L=True):
+        N = self.N
+        a = np.empty(N) if alpha else None
+        w = np.empty(N) if sW else None
+        Lm = np.empty((N, N)) if L else None
+        rc = self.ctx._lib.gpc_post_fetch(self._h, int(s), _ptr(a), _ptr(w), _ptr(Lm))
+        self.ctx._check(rc, "gpc_post_fetch")
+        return a, w, Lm
+
+    def predict(self, x_star):
+        xs = _f64(x_star)
+        M = xs.shape[0]
+        fmu = np.empty((M, self.S))
+        fs2 = np.empty((M, self.S))
+        rc = self.ctx._lib.gpc_predict(self._h, _ptr(xs), M, _ptr(fmu), _ptr(fs2))
+        self.ctx._check(rc, "gpc_predict")
+        return fmu, fs2
+
+    def free(self):
+        if self._h:
+            self.ctx._lib.gpc_post_free(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            if self.ctx._h:
+                self.free()
+        except Exception:
+            pass
+
+
+_contexts = {}
+
+
+def default_device() -> int:
+    return int(os.environ.get("GPYREG_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+
+
+def context(device: int | None = None) -> Context:
+    """Process-wide context of a device (created on first use)."""
+    dev = default_device() if device is None else int(device)
+    ctx = _contexts.get(dev)
+    if ctx is None or ctx._h is None:
+        ctx = Context(dev)
+        _contexts[dev] = ctx
+    return ctx

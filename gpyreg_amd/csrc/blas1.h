@@ -1,0 +1,196 @@
+// blas1.h -- bandwidth-bound helpers around the factorization (all batched on blockIdx.y):
+// triangular matrix-vector products with W = L^-1 (they replace the reference's
+// solve_triangular calls at gaussian_process.py:2455-2465), dot products, column sums
+// for predict (gaussian_process.py:1747-1764) and small utility copies.
+#pragma once
+#include "common.h"
+
+namespace gpc {
+
+// z[b][i] = sum_{k<=i} W[b][i][k] * r[b][k].   One wave per row, 4 rows per block.
+// The diagonal tile of W is zero above the diagonal, so the row is read up to the end
+// of its 128-wide diagonal tile without masking.   grid = (npad/4, batch)
+template <typename T>
+__global__ __launch_bounds__(256) void trmv_kernel(const T* __restrict__ W_all, long long sW, int ldw,
+                                                   const double* __restrict__ r_all, int npad,
+                                                   double* __restrict__ z_all) {
+  using vec_t = typename MM<T>::vec_t;
+  constexpr int VEC = MM<T>::VEC;
+  const int b = blockIdx.y, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const T* Wr = W_all + (size_t)b * sW + (size_t)i * ldw;
+  const double* r = r_all + (size_t)b * npad;
+  const int kend = ((i >> 7) + 1) << 7;
+  double s = 0.0;
+  for (int k = lane * VEC; k < kend; k += 64 * VEC) {
+    const vec_t wv = *reinterpret_cast<const vec_t*>(Wr + k);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s += (double)wv[e] * r[k + e];
+  }
+  s = wave_sum(s);
+  if (lane == 0) z_all[(size_t)b * npad + i] = s;
+}
+
+// out[b][k] = scale[b] * sum_{i>=k} W[b][i][k] * z[b][i]   (W^T z).  grid = (npad/64, batch)
+// scale[b] = 1/sp[b][SP_SL] when sp != nullptr.
+template <typename T>
+__global__ __launch_bounds__(256) void trmv_t_kernel(const T* __restrict__ W_all, long long sW, int ldw,
+                                                     const double* __restrict__ z_all, int npad,
+                                                     const double* __restrict__ sp_all, int sp_stride,
+                                                     int sp_off, double* __restrict__ out_all) {
+  __shared__ double red[4][64];
+  const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane;
+  const int istart = (blockIdx.x * 64) & ~127;
+  const T* Wb = W_all + (size_t)b * sW;
+  const double* z = z_all + (size_t)b * npad;
+  double s = 0.0;
+  for (int i = istart + w; i < npad; i += 4) s += (double)Wb[(size_t)i * ldw + k] * z[i];
+  red[w][lane] = s;
+  __syncthreads();
+  if (w == 0) {
+    double v = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    if (sp_all) v /= sp_all[(size_t)b * sp_stride + sp_off];
+    out_all[(size_t)b * npad + k] = v;
+  }
+}
+
+// out[b] = sum_i x[b][i] * y[b][i].   grid = (1, batch)
+__global__ __launch_bounds__(256) void dot_kernel(const double* __restrict__ x, const double* __restrict__ y,
+                                                  int n, int stride, double* __restrict__ out) {
+  __shared__ double sh4[4];
+  const int b = blockIdx.y;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += x[(size_t)b * stride + i] * y[(size_t)b * stride + i];
+  s = block_sum_256(s, sh4);
+  if (threadIdx.x == 0) out[b] = s;
+}
+
+// out[b][p] = sum_i Mat[b][i][p] * vec[b][i]   (Mat: n x P row-major; vec stride vstride)
+// grid = (P, batch)
+__global__ __launch_bounds__(256) void mat_t_vec_kernel(const double* __restrict__ Mat, int n, int P,
+                                                        const double* __restrict__ vec, int vstride,
+                                                        double* __restrict__ out) {
+  __shared__ double sh4[4];
+  const int p = blockIdx.x, b = blockIdx.y;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256)
+    s += Mat[((size_t)b * n + i) * P + p] * vec[(size_t)b * vstride + i];
+  s = block_sum_256(s, sh4);
+  if (threadIdx.x == 0) out[(size_t)b * P + p] = s;
+}
+
+// out[b][j] = sum_i A[b][i][j] * Bm[b][i][j]   over rows < nrows.  grid = (mpad/64, batch)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_prod_kernel(const T* __restrict__ A_all, long long sA,
+                                                          const T* __restrict__ B_all, long long sB,
+                                                          int ld, int nrows, int mpad,
+                                                          double* __restrict__ out_all) {
+  __shared__ double red[4][64];
+  const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + lane;
+  const T* A = A_all + (size_t)b * sA;
+  const T* Bm = B_all + (size_t)b * sB;
+  double s = 0.0;
+  for (int i = w; i < nrows; i += 4) s += (double)A[(size_t)i * ld + j] * (double)Bm[(size_t)i * ld + j];
+  red[w][lane] = s;
+  __syncthreads();
+  if (w == 0) out_all[(size_t)b * mpad + j] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+}
+
+// out[b][j] = sum_i A[b][i][j] * v[b][i]   (A^T v, A: nrows x mpad).  grid = (mpad/64, batch)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ A_all, long long sA, int ld,
+                                                         const double* __restrict__ v_all, int vstride,
+                                                         int nrows, int mpad, double* __restrict__ out_all) {
+  __shared__ double red[4][64];
+  const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + lane;
+  const T* A = A_all + (size_t)b * sA;
+  const double* v = v_all + (size_t)b * vstride;
+  double s = 0.0;
+  for (int i = w; i < nrows; i += 4) s += (double)A[(size_t)i * ld + j] * v[i];
+  red[w][lane] = s;
+  __syncthreads();
+  if (w == 0) out_all[(size_t)b * mpad + j] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+}
+
+// dst[i][j] (double, n x n dense) = j <= i ? src[i][j] : 0       (clean lower factor)
+// mode 1: dst = -(symmetrised lower src);  mode 2: plain full copy (low-noise Posterior.L)
+// grid = (ceil(n/64), ceil(n/4)), block = (64, 4)
+template <typename T>
+__global__ void extract_kernel(const T* __restrict__ src, int ld, int n, int mode,
+                               double* __restrict__ dst) {
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  const int i = blockIdx.y * 4 + threadIdx.y;
+  if (i >= n || j >= n) return;
+  double v;
+  if (mode == 0)
+    v = (j <= i) ? (double)src[(size_t)i * ld + j] : 0.0;
+  else if (mode == 1)
+    v = -(double)((j <= i) ? src[(size_t)i * ld + j] : src[(size_t)j * ld + i]);
+  else
+    v = (double)src[(size_t)i * ld + j];
+  dst[(size_t)i * n + j] = v;
+}
+
+// in place on a padded square buffer: make it the full symmetric NEGATED matrix from
+// its lower triangle (the low-noise "L = -inv" of gaussian_process.py:2441-2448).
+// grid = (npad/64, npad/4, batch), block = (64, 4)
+template <typename T>
+__global__ void neg_sym_kernel(T* __restrict__ buf_all, long long sB, int ld, int npad) {
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  const int i = blockIdx.y * 4 + threadIdx.y;
+  if (i >= npad || j > i) return;
+  T* buf = buf_all + (size_t)blockIdx.z * sB;
+  const T v = -buf[(size_t)i * ld + j];
+  buf[(size_t)i * ld + j] = v;
+  if (j < i) buf[(size_t)j * ld + i] = v;
+}
+
+// dst[b][i][j] = (T) src[i][j] for i,j < n else identity   (debug/test upload helper)
+template <typename T>
+__global__ void pad_load_kernel(const double* __restrict__ src, int n, int npad, T* __restrict__ dst) {
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  const int i = blockIdx.y * 4 + threadIdx.y;
+  if (i >= npad || j >= npad) return;
+  double v = (i < n && j < n) ? src[(size_t)i * n + j] : ((i == j) ? 1.0 : 0.0);
+  dst[(size_t)i * npad + j] = (T)v;
+}
+
+// copy the 128 x 128 blocks strictly below the diagonal blocks... generic rect copy:
+// dst[b][r][c] = src[b][r][c] for r < rows, c < cols.  grid = (cols/64, rows/4, batch)
+template <typename T>
+__global__ void rect_copy_kernel(const T* __restrict__ src, long long sS, int lds_, T* __restrict__ dst,
+                                 long long sD, int ldd, int rows, int cols) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  const int r = blockIdx.y * 4 + threadIdx.y;
+  if (r >= rows || c >= cols) return;
+  dst[(size_t)blockIdx.z * sD + (size_t)r * ldd + c] = src[(size_t)blockIdx.z * sS + (size_t)r * lds_ + c];
+}
+
+// register-resident MFMA issue loop: the measured ceiling the roofline is quoted against
+template <typename T>
+__global__ __launch_bounds__(256) void mfma_peak_kernel(T* out, int iters, long long* clk) {
+  using acc_t = typename MM<T>::acc_t;
+  acc_t acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = acc_t{0, 0, 0, 0};
+  T a = (T)(threadIdx.x * 1e-3), bq = (T)(1.0 + threadIdx.x * 1e-4);
+  const long long c0 = clock64(), w0 = wall_clock64();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = MM<T>::mma(a, bq, acc[i]);
+  }
+  const long long c1 = clock64(), w1 = wall_clock64();
+  if (clk && blockIdx.x == 0 && threadIdx.x == 0) {
+    clk[0] = c1 - c0;  // shader cycles for iters*8 MFMAs of this wave
+    clk[1] = w1 - w0;  // 100 MHz reference ticks
+  }
+  T s = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+}  // namespace gpc

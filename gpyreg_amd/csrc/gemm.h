@@ -1,0 +1,241 @@
+// gemm.h -- batched, tiled MFMA GEMM with per-tile k-ranges (the N^3 engine).
+//
+//   C[b] (M x N) = beta * C[b] + alpha * Aop[b] (M x K) * Bop[b] (K x N),   b = blockIdx.y
+//
+// Every O(N^3) stage of the GP path is one or more launches of this kernel
+// (see plan.h): the trsm of the blocked Cholesky (as a product with the inverse of
+// the diagonal block), its syrk trailing update, the triangular inverse, the
+// W^T W product that yields (K + sigma^2 I)^-1, and the K* solves of predict.
+//
+// Design (CDNA4, 64-wide waves):
+//   * block tile 128 x 128, 256 threads = 4 waves, each wave a 64 x 64 sub-tile held
+//     as 4 x 4 accumulators of v_mfma_f64_16x16x4_f64 (or the f32 form): 128 VGPRs.
+//   * operands are staged global -> registers -> LDS in k-slabs of 16, double
+//     buffered, one barrier per slab; the next slab's global loads are issued before
+//     the current slab's MFMAs so HBM/L2 latency hides under 64 MFMAs per wave.
+//   * an operand may be stored "m-major" ([row][k], k contiguous) or "k-major"
+//     ([k][row], row contiguous).  Both are copied straight (16-byte vectors,
+//     coalesced) into an LDS image of the same orientation; only the fragment
+//     address differs.  LDS strides (17 and 144 elements) make every ds_read_b64
+//     fragment read bank-conflict free.
+//   * triangular structure is expressed as a per-tile k-range [k0, k1) so that tiles
+//     never multiply by the zero half of a triangular operand, and `lower_only`
+//     launches only the tiles on or below the diagonal.
+#pragma once
+#include "common.h"
+
+namespace gpc {
+
+constexpr int BKT = 16;          // k-slab per LDS stage
+constexpr int LDQ = BKT + 1;     // stride of an m-major LDS image  [128][17]
+constexpr int LDP = TILE + 16;   // stride of a  k-major LDS image  [16][144]
+constexpr int OPSZ = BKT * LDP;  // elements reserved per operand per stage (>= 128*17)
+
+enum { KLO_ZERO = 0, KLO_ROW = 1, KLO_COL = 2 };  // k0 = 0 | ti*128 | tj*128
+enum { KHI_FULL = 0, KHI_ROW = 1, KHI_COL = 2 };  // k1 = K | (ti+1)*128 | (tj+1)*128
+
+struct GemmArgs {
+  const void* A;
+  const void* B;
+  void* C;
+  long long sA, sB, sC;  // batch strides in elements
+  int lda, ldb, ldc;
+  int M, N, K;  // multiples of 128
+  double alpha;
+  int beta;  // 0 or 1
+  int klo, khi, lower_only;
+  int tiles_n;
+};
+
+template <typename T, bool KM>
+__device__ __forceinline__ void g2r(typename MM<T>::vec_t (&r)[(TILE * BKT) / (256 * MM<T>::VEC)],
+                                    const T* __restrict__ g, int ld, int r0, int k0, int t) {
+  using vec_t = typename MM<T>::vec_t;
+  constexpr int VEC = MM<T>::VEC;
+  constexpr int NV = (TILE * BKT) / (256 * VEC);
+  if constexpr (!KM) {  // stored [row][k]
+    constexpr int TPR = BKT / VEC;   // threads per row
+    constexpr int RPP = 256 / TPR;   // rows per pass
+#pragma unroll
+    for (int p = 0; p < NV; ++p) {
+      const int row = t / TPR + p * RPP;
+      const int kc = (t % TPR) * VEC;
+      r[p] = *reinterpret_cast<const vec_t*>(g + (size_t)(r0 + row) * ld + k0 + kc);
+    }
+  } else {  // stored [k][row]
+    constexpr int VPR = TILE / VEC;  // vectors per k-row
+#pragma unroll
+    for (int p = 0; p < NV; ++p) {
+      const int v = t + 256 * p;
+      const int k = v / VPR;
+      const int mc = (v % VPR) * VEC;
+      r[p] = *reinterpret_cast<const vec_t*>(g + (size_t)(k0 + k) * ld + r0 + mc);
+    }
+  }
+}
+
+template <typename T, bool KM>
+__device__ __forceinline__ void r2s(T* __restrict__ s,
+                                    const typename MM<T>::vec_t (&r)[(TILE * BKT) / (256 * MM<T>::VEC)],
+                                    int t) {
+  using vec_t = typename MM<T>::vec_t;
+  constexpr int VEC = MM<T>::VEC;
+  constexpr int NV = (TILE * BKT) / (256 * VEC);
+  if constexpr (!KM) {
+    constexpr int TPR = BKT / VEC;
+    constexpr int RPP = 256 / TPR;
+#pragma unroll
+    for (int p = 0; p < NV; ++p) {
+      const int row = t / TPR + p * RPP;
+      const int kc = (t % TPR) * VEC;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) s[row * LDQ + kc + e] = r[p][e];
+    }
+  } else {
+    constexpr int VPR = TILE / VEC;
+#pragma unroll
+    for (int p = 0; p < NV; ++p) {
+      const int v = t + 256 * p;
+      const int k = v / VPR;
+      const int mc = (v % VPR) * VEC;
+      *reinterpret_cast<vec_t*>(s + k * LDP + mc) = r[p];
+    }
+  }
+}
+
+template <typename T, bool KM>
+__device__ __forceinline__ T frag(const T* __restrict__ s, int r0, int kk, int lane) {
+  if constexpr (!KM)
+    return s[(r0 + (lane & 15)) * LDQ + kk + (lane >> 4)];
+  else
+    return s[(kk + (lane >> 4)) * LDP + r0 + (lane & 15)];
+}
+
+__device__ __forceinline__ void tri_tile(int tile, int& ti, int& tj) {
+  int i = (int)((sqrtf(8.f * (float)tile + 1.f) - 1.f) * 0.5f);
+  while (i * (i + 1) / 2 > tile) --i;
+  while ((i + 1) * (i + 2) / 2 <= tile) ++i;
+  ti = i;
+  tj = tile - i * (i + 1) / 2;
+}
+
+template <typename T, bool AKM, bool BKM>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
+  using acc_t = typename MM<T>::acc_t;
+  using vec_t = typename MM<T>::vec_t;
+  constexpr int NV = (TILE * BKT) / (256 * MM<T>::VEC);
+  __shared__ __attribute__((aligned(16))) T smem[4 * OPSZ];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
+
+  int ti, tj;
+  if (g.lower_only) {
+    tri_tile(blockIdx.x, ti, tj);
+  } else {
+    ti = blockIdx.x / g.tiles_n;
+    tj = blockIdx.x % g.tiles_n;
+  }
+  const int m0 = ti * TILE, n0 = tj * TILE;
+  int k0 = g.klo == KLO_ROW ? m0 : (g.klo == KLO_COL ? n0 : 0);
+  int k1 = g.khi == KHI_ROW ? m0 + TILE : (g.khi == KHI_COL ? n0 + TILE : g.K);
+  if (k1 > g.K) k1 = g.K;
+  const int nk = (k1 - k0) / BKT;
+
+  const T* __restrict__ A = reinterpret_cast<const T*>(g.A) + (size_t)blockIdx.y * g.sA;
+  const T* __restrict__ B = reinterpret_cast<const T*>(g.B) + (size_t)blockIdx.y * g.sB;
+  T* __restrict__ C = reinterpret_cast<T*>(g.C) + (size_t)blockIdx.y * g.sC;
+
+  acc_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+
+  if (nk > 0) {
+    vec_t ra[NV], rb[NV];
+    g2r<T, AKM>(ra, A, g.lda, m0, k0, t);
+    g2r<T, BKM>(rb, B, g.ldb, n0, k0, t);
+    r2s<T, AKM>(smem, ra, t);
+    r2s<T, BKM>(smem + OPSZ, rb, t);
+    __syncthreads();
+    for (int it = 0; it < nk; ++it) {
+      const int cur = it & 1;
+      const T* a_s = smem + cur * 2 * OPSZ;
+      const T* b_s = a_s + OPSZ;
+      const bool more = (it + 1 < nk);
+      if (more) {
+        g2r<T, AKM>(ra, A, g.lda, m0, k0 + (it + 1) * BKT, t);
+        g2r<T, BKM>(rb, B, g.ldb, n0, k0 + (it + 1) * BKT, t);
+      }
+#pragma unroll
+      for (int kk = 0; kk < BKT; kk += 4) {
+        T af[4], bf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = frag<T, AKM>(a_s, wr * 64 + i * 16, kk, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[j] = frag<T, BKM>(b_s, wc * 64 + j * 16, kk, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = MM<T>::mma(af[i], bf[j], acc[i][j]);
+      }
+      if (more) {
+        T* a_n = smem + (cur ^ 1) * 2 * OPSZ;
+        r2s<T, AKM>(a_n, ra, t);
+        r2s<T, BKM>(a_n + OPSZ, rb, t);
+      }
+      __syncthreads();
+    }
+  }
+
+  const T alpha = (T)g.alpha;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wr * 64 + i * 16 + MM<T>::row_of(lane, r);
+        const int col = n0 + wc * 64 + j * 16 + (lane & 15);
+        T* p = C + (size_t)row * g.ldc + col;
+        T v = alpha * acc[i][j][r];
+        if (g.beta) v += *p;
+        *p = v;
+      }
+}
+
+template <typename T>
+inline hipError_t launch_gemm(hipStream_t st, GemmArgs g, bool akm, bool bkm, int batch) {
+  const int tm = g.M / TILE, tn = g.N / TILE;
+  g.tiles_n = tn;
+  const int ntiles = g.lower_only ? tm * (tm + 1) / 2 : tm * tn;
+  if (ntiles <= 0 || batch <= 0) return hipSuccess;
+  dim3 grid(ntiles, batch), block(256);
+  if (!akm && !bkm)
+    hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, block, 0, st, g);
+  else if (!akm && bkm)
+    hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, block, 0, st, g);
+  else if (akm && bkm)
+    hipLaunchKernelGGL((gemm_kernel<T, true, true>), grid, block, 0, st, g);
+  else
+    hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, block, 0, st, g);
+  return hipGetLastError();
+}
+
+// algorithmic flops of one launch (for the roofline bookkeeping)
+inline double gemm_flops(const GemmArgs& g, int batch) {
+  const int tm = g.M / TILE, tn = g.N / TILE;
+  double f = 0;
+  for (int ti = 0; ti < tm; ++ti)
+    for (int tj = 0; tj < tn; ++tj) {
+      if (g.lower_only && tj > ti) continue;
+      int k0 = g.klo == KLO_ROW ? ti * TILE : (g.klo == KLO_COL ? tj * TILE : 0);
+      int k1 = g.khi == KHI_ROW ? (ti + 1) * TILE : (g.khi == KHI_COL ? (tj + 1) * TILE : g.K);
+      if (k1 > g.K) k1 = g.K;
+      if (k1 > k0) f += 2.0 * TILE * TILE * (k1 - k0);
+    }
+  return f * batch;
+}
+
+}  // namespace gpc

@@ -1,0 +1,1086 @@
+// gpcore.hip -- libgpcore.so: C ABI (include/gpcore.h) over the HIP kernels.
+//
+// Path implemented (reference lines in parentheses):
+//   covariance.compute              (covariance_functions.py:135-367, isotropic_...:104-221)
+//   GP.__core_computation           (gaussian_process.py:2357-2521)
+//   GP.update full-recompute loop   (gaussian_process.py:870-884)   -> gpc_posterior_batch
+//   GP.predict K* solves            (gaussian_process.py:1741-1764) -> gpc_predict
+// Data layout in HBM: every N x N matrix is row-major, padded to a multiple of 128 with
+// an identity block (exactly inert for Cholesky, inverse, log-det and traces), one slab
+// per hyperparameter sample, samples contiguous (batch stride = npad^2).
+#include "../../include/gpcore.h"
+
+#include <algorithm>
+#include <cmath>
+#include <mutex>
+
+#include "blas1.h"
+#include "common.h"
+#include "covfun.h"
+#include "gemm.h"
+#include "leaf.h"
+#include "plan.h"
+
+using namespace gpc;
+
+namespace {
+
+std::string g_create_err;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  hipError_t ensure(size_t need) {
+    if (need <= bytes) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    hipError_t e = hipMalloc(&p, need);
+    if (e == hipSuccess) bytes = need;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  template <typename U>
+  U* as() const {
+    return reinterpret_cast<U*>(p);
+  }
+};
+
+}  // namespace
+
+struct gpc_ctx {
+  int device = 0;
+  hipStream_t st = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  std::string err;
+  std::string devinfo;
+  // resident training data
+  int N = 0, D = 0, npad = 0;
+  DevBuf dX;  // N x D
+  std::vector<double> hy;
+  // workspace
+  DevBuf mA, mW, mT;             // matrices of the current chunk
+  DevBuf xs, spb, mulb, divb;    // scaled inputs and per-sample scalars
+  DevBuf dvec, rvec, zvec, avec; // per-sample vectors (npad each)
+  DevBuf scal;                   // logdet | quad | (ints) info
+  DevBuf parts, gout, diagq;     // trace pass
+  DevBuf dmb, dsn2b, mg, ng;     // mean / noise gradient inputs and outputs
+  DevBuf ks, vb, xss, pout;      // predict
+  DevBuf dbg1, dbg2, dbg3;       // debug hooks / fetch staging
+  double ms_total = 0, ms_factor = 0;
+  double last_flops = 0;
+};
+
+struct gpc_post {
+  gpc_ctx* ctx = nullptr;
+  int dtype = GPC_F64;
+  int S = 0, N = 0, D = 0, npad = 0;
+  CovDesc cd{};
+  DevBuf A, W;  // per-sample: A = Cholesky factor (L_chol) or -(K+Sigma)^-1 ; W = L^-1
+  DevBuf alpha; // S x npad (double)
+  std::vector<double> sp, mul, dv;  // host copies of per-sample scalars (SP_STRIDE), scaling
+  std::vector<double> sW, mult;
+  std::vector<int> lchol, info;
+};
+
+#define HIPCHK(ctx, expr)                                                                   \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess) {                                                                 \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                       \
+      return -1;                                                                            \
+    }                                                                                       \
+  } while (0)
+
+#define FAIL(ctx, msg)   \
+  do {                   \
+    (ctx)->err = (msg);  \
+    return -2;           \
+  } while (0)
+
+namespace {
+
+int cov_count_of(int kind, int D) {
+  switch (kind) {
+    case K_SE:
+    case K_MATERN:
+      return D + 1;
+    case K_RQ:
+      return D + 2;
+    case K_SE_ISO:
+    case K_MATERN_ISO:
+      return 2;
+    default:
+      return -1;
+  }
+}
+
+bool valid_kernel(int kind, int degree) {
+  if (kind < K_SE || kind > K_MATERN_ISO) return false;
+  if ((kind == K_MATERN || kind == K_MATERN_ISO) && degree != 1 && degree != 3 && degree != 5) return false;
+  return true;
+}
+
+// input scaling exactly as the reference applies it before the distance computation
+void scaling_of(int kind, int degree, int D, const double* hyp, double* mul, double* dv, double* sf2,
+                double* rqa) {
+  const double snu = std::sqrt((double)degree);
+  *rqa = 1.0;
+  if (cov_is_iso(kind)) {
+    const double ell = std::exp(hyp[0]);
+    *sf2 = std::exp(2 * hyp[1]);
+    for (int h = 0; h < D; ++h) {
+      mul[h] = (kind == K_MATERN_ISO) ? snu : 1.0;  // X * sqrt(nu) / ell   |  X / ell
+      dv[h] = ell;
+    }
+    return;
+  }
+  *sf2 = std::exp(2 * hyp[D]);
+  if (kind == K_RQ) *rqa = std::exp(hyp[D + 1]);
+  for (int h = 0; h < D; ++h) {
+    const double ell = std::exp(hyp[h]);
+    if (kind == K_SE) {
+      mul[h] = 1.0;  // X / ell
+      dv[h] = ell;
+    } else if (kind == K_MATERN) {
+      mul[h] = snu / ell;  // X @ diag(sqrt(nu)/ell)
+      dv[h] = 1.0;
+    } else {
+      mul[h] = 1.0 / ell;  // X @ diag(1/ell)
+      dv[h] = 1.0;
+    }
+  }
+}
+
+// host-side description of a batch of hyperparameter samples
+struct Batch {
+  int S = 0, N = 0, D = 0, npad = 0;
+  CovDesc cd{};
+  bool vec_noise = false;
+  const double* hyp_cov = nullptr;
+  const double* m = nullptr;
+  const double* sn2 = nullptr;
+  const double* y = nullptr;
+  std::vector<double> mul, dv, sp, dvec, r;
+  std::vector<double> smin, mult, sl;
+  std::vector<int> lchol, tries, info;
+
+  void init() {
+    mul.assign((size_t)S * D, 1.0);
+    dv.assign((size_t)S * D, 1.0);
+    sp.assign((size_t)S * SP_STRIDE, 0.0);
+    dvec.assign((size_t)S * npad, 1.0);
+    r.assign((size_t)S * npad, 0.0);
+    smin.assign(S, 0.0);
+    mult.assign(S, 1.0);
+    sl.assign(S, 1.0);
+    lchol.assign(S, 0);
+    tries.assign(S, 0);
+    info.assign(S, 0);
+    for (int s = 0; s < S; ++s) {
+      double sf2, rqa;
+      scaling_of(cd.kind, cd.degree, D, hyp_cov + (size_t)s * cd.cov_N, &mul[(size_t)s * D],
+                 &dv[(size_t)s * D], &sf2, &rqa);
+      sp[(size_t)s * SP_STRIDE + SP_SF2] = sf2;
+      sp[(size_t)s * SP_STRIDE + SP_RQA] = rqa;
+      const double* sn = sn2 + (size_t)s * (vec_noise ? N : 1);
+      double mn = sn[0];
+      if (vec_noise)
+        for (int i = 1; i < N; ++i) mn = std::min(mn, sn[i]);
+      smin[s] = mn;
+      lchol[s] = (mn >= 1e-6) ? 1 : 0;  // gaussian_process.py:2404
+      for (int i = 0; i < N; ++i) r[(size_t)s * npad + i] = y[i] - m[(size_t)s * N + i];
+      apply_mult(s);
+    }
+  }
+
+  // (re)derive the scaled system of sample s for its current jitter multiplier
+  // (gaussian_process.py:2406-2439)
+  void apply_mult(int s) {
+    const double* sn = sn2 + (size_t)s * (vec_noise ? N : 1);
+    double* d = &dvec[(size_t)s * npad];
+    if (lchol[s]) {
+      const double sn2_div = smin[s];  // scalar noise: the value itself
+      sl[s] = sn2_div * mult[s];
+      for (int i = 0; i < N; ++i) d[i] = vec_noise ? sn[i] / sn2_div : 1.0;
+    } else {
+      sl[s] = 1.0;
+      for (int i = 0; i < N; ++i) d[i] = mult[s] * (vec_noise ? sn[i] : sn[0]);
+    }
+    for (int i = N; i < npad; ++i) d[i] = 1.0;
+    sp[(size_t)s * SP_STRIDE + SP_KSCALE] = sl[s];  // K is DIVIDED by this
+    sp[(size_t)s * SP_STRIDE + SP_SL] = sl[s];
+  }
+};
+
+
+enum Mode { MODE_NLL = 0, MODE_GRAD = 1, MODE_POST = 2 };
+
+template <typename T>
+struct Pipe {
+  gpc_ctx* c;
+  Batch* B;
+  Mode mode;
+  // matrices for the chunk being processed (sample 0 of the chunk)
+  T* A;
+  T* W;
+  T* Tm;
+  long long sM;
+  // gradient side inputs (whole batch, host pointers)
+  const double* dm = nullptr;
+  int mean_N = 0;
+  const double* dsn2 = nullptr;
+  int noise_N = 0;
+  // outputs (whole batch, host)
+  std::vector<double> logdet, quad, G, mg, ng;
+
+  int P() const { return B->cd.cov_N + 1; }
+
+  // run the device pipeline for samples [s0, s0+cnt) whose matrices start at slot `slot`
+  int run(int s0, int cnt, int slot) {
+    Batch& b = *B;
+    const int npad = b.npad, N = b.N, D = b.D;
+    hipStream_t st = c->st;
+    T* Ac = A + (size_t)slot * sM;
+    T* Wc = W + (size_t)slot * sM;
+    T* Tc = Tm + (size_t)slot * sM;
+    const size_t vb = (size_t)npad * sizeof(double);
+
+    HIPCHK(c, c->xs.ensure((size_t)cnt * npad * D * sizeof(double)));
+    HIPCHK(c, c->spb.ensure((size_t)cnt * SP_STRIDE * sizeof(double)));
+    HIPCHK(c, c->mulb.ensure((size_t)cnt * D * sizeof(double)));
+    HIPCHK(c, c->divb.ensure((size_t)cnt * D * sizeof(double)));
+    HIPCHK(c, c->dvec.ensure(cnt * vb));
+    HIPCHK(c, c->rvec.ensure(cnt * vb));
+    HIPCHK(c, c->zvec.ensure(cnt * vb));
+    HIPCHK(c, c->avec.ensure(cnt * vb));
+    HIPCHK(c, c->scal.ensure((size_t)cnt * (2 * sizeof(double) + sizeof(int)) + 64));
+    double* d_logdet = c->scal.as<double>();
+    double* d_quad = d_logdet + cnt;
+    int* d_info = reinterpret_cast<int*>(d_quad + cnt);
+
+    HIPCHK(c, hipEventRecord(c->ev[0], st));
+    HIPCHK(c, hipMemcpyAsync(c->spb.p, &b.sp[(size_t)s0 * SP_STRIDE], (size_t)cnt * SP_STRIDE * 8,
+                             hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->mulb.p, &b.mul[(size_t)s0 * D], (size_t)cnt * D * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->divb.p, &b.dv[(size_t)s0 * D], (size_t)cnt * D * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->dvec.p, &b.dvec[(size_t)s0 * npad], cnt * vb, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->rvec.p, &b.r[(size_t)s0 * npad], cnt * vb, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemsetAsync(c->scal.p, 0, (size_t)cnt * (2 * sizeof(double) + sizeof(int)), st));
+
+    {
+      const long long tot = (long long)npad * D;
+      dim3 grid((unsigned)((tot + 255) / 256), cnt);
+      hipLaunchKernelGGL(scale_x_kernel, grid, dim3(256), 0, st, c->dX.as<double>(), N, npad, D,
+                         c->mulb.as<double>(), c->divb.as<double>(), c->xs.as<double>());
+    }
+    const int t64 = npad / CT, ntl = t64 * (t64 + 1) / 2;
+    hipLaunchKernelGGL((build_kernel<T>), dim3(ntl, cnt), dim3(256), 0, st, b.cd, c->xs.as<double>(),
+                       c->spb.as<double>(), c->dvec.as<double>(), N, npad, Ac, sM, npad);
+    HIPCHK(c, hipGetLastError());
+
+    HIPCHK(c, hipEventRecord(c->ev[1], st));
+    Factor<T> F;
+    F.st = st;
+    F.batch = cnt;
+    F.npad = npad;
+    F.A = Ac;
+    F.W = Wc;
+    F.Tm = Tc;
+    F.sA = F.sW = F.sT = sM;
+    F.logdet = d_logdet;
+    F.info = d_info;
+    F.potrf_inv(0, npad, true, mode == MODE_POST);
+    if (mode == MODE_GRAD) F.lauum(Tc, sM);
+    HIPCHK(c, F.err);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev[2], st));
+    c->last_flops += F.flops;
+
+    // z = W r ; quad = z.z ; alpha = W^T z / sl
+    hipLaunchKernelGGL((trmv_kernel<T>), dim3(npad / 4, cnt), dim3(256), 0, st, (const T*)Wc, sM, npad,
+                       c->rvec.as<double>(), npad, c->zvec.as<double>());
+    hipLaunchKernelGGL(dot_kernel, dim3(1, cnt), dim3(256), 0, st, c->zvec.as<double>(),
+                       c->zvec.as<double>(), npad, npad, d_quad);
+    if (mode != MODE_NLL) {
+      hipLaunchKernelGGL((trmv_t_kernel<T>), dim3(npad / 64, cnt), dim3(256), 0, st, (const T*)Wc, sM,
+                         npad, c->zvec.as<double>(), npad, c->spb.as<double>(), (int)SP_STRIDE, (int)SP_SL,
+                         c->avec.as<double>());
+    }
+    HIPCHK(c, hipGetLastError());
+
+    const int Pn = P();
+    if (mode == MODE_GRAD) {
+      HIPCHK(c, c->parts.ensure((size_t)cnt * ntl * Pn * sizeof(double)));
+      HIPCHK(c, c->gout.ensure((size_t)cnt * Pn * sizeof(double)));
+      HIPCHK(c, c->diagq.ensure(cnt * vb));
+      hipLaunchKernelGGL((trace_kernel<T>), dim3(ntl, cnt), dim3(256), 4 * Pn * sizeof(double), st, b.cd,
+                         c->xs.as<double>(), c->spb.as<double>(), c->avec.as<double>(), N, npad,
+                         (const T*)Tc, sM, npad, c->parts.as<double>(), ntl, c->diagq.as<double>());
+      hipLaunchKernelGGL(reduce_parts_kernel, dim3(Pn, cnt), dim3(256), 0, st, c->parts.as<double>(), ntl,
+                         Pn, c->gout.as<double>());
+      HIPCHK(c, hipGetLastError());
+      if (mean_N > 0) {
+        HIPCHK(c, c->dmb.ensure((size_t)cnt * N * mean_N * 8));
+        HIPCHK(c, c->mg.ensure((size_t)cnt * mean_N * 8));
+        HIPCHK(c, hipMemcpyAsync(c->dmb.p, dm + (size_t)s0 * N * mean_N, (size_t)cnt * N * mean_N * 8,
+                                 hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(mat_t_vec_kernel, dim3(mean_N, cnt), dim3(256), 0, st, c->dmb.as<double>(), N,
+                           mean_N, c->avec.as<double>(), npad, c->mg.as<double>());
+      }
+      if (noise_N > 0 && b.vec_noise) {
+        HIPCHK(c, c->dsn2b.ensure((size_t)cnt * N * noise_N * 8));
+        HIPCHK(c, c->ng.ensure((size_t)cnt * noise_N * 8));
+        HIPCHK(c, hipMemcpyAsync(c->dsn2b.p, dsn2 + (size_t)s0 * N * noise_N, (size_t)cnt * N * noise_N * 8,
+                                 hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(mat_t_vec_kernel, dim3(noise_N, cnt), dim3(256), 0, st, c->dsn2b.as<double>(), N,
+                           noise_N, c->diagq.as<double>(), npad, c->ng.as<double>());
+      }
+      HIPCHK(c, hipGetLastError());
+    }
+    HIPCHK(c, hipEventRecord(c->ev[3], st));
+
+    // results back
+    std::vector<int> hinfo(cnt);
+    HIPCHK(c, hipMemcpyAsync(&logdet[s0], d_logdet, cnt * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(&quad[s0], d_quad, cnt * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(hinfo.data(), d_info, cnt * sizeof(int), hipMemcpyDeviceToHost, st));
+    if (mode == MODE_GRAD) {
+      HIPCHK(c, hipMemcpyAsync(&G[(size_t)s0 * Pn], c->gout.p, (size_t)cnt * Pn * 8, hipMemcpyDeviceToHost, st));
+      if (mean_N > 0)
+        HIPCHK(c, hipMemcpyAsync(&mg[(size_t)s0 * mean_N], c->mg.p, (size_t)cnt * mean_N * 8,
+                                 hipMemcpyDeviceToHost, st));
+      if (noise_N > 0 && b.vec_noise)
+        HIPCHK(c, hipMemcpyAsync(&ng[(size_t)s0 * noise_N], c->ng.p, (size_t)cnt * noise_N * 8,
+                                 hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(c, hipStreamSynchronize(st));
+    for (int i = 0; i < cnt; ++i) b.info[s0 + i] = hinfo[i];
+    float t03 = 0, t12 = 0;
+    (void)hipEventElapsedTime(&t03, c->ev[0], c->ev[3]);
+    (void)hipEventElapsedTime(&t12, c->ev[1], c->ev[2]);
+    c->ms_total += t03;
+    c->ms_factor += t12;
+    return 0;
+  }
+
+  // one sample again and again with the x10 jitter escalation (gaussian_process.py:2413-2421)
+  int retry(int s, int slot) {
+    Batch& b = *B;
+    b.tries[s] = 1;
+    while (b.info[s] != 0 && b.tries[s] < 10) {
+      b.mult[s] *= 10.0;
+      b.apply_mult(s);
+      b.tries[s] += 1;
+      int rc = run(s, 1, slot);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+};
+
+size_t free_device_bytes() {
+  size_t f = 0, t = 0;
+  if (hipMemGetInfo(&f, &t) != hipSuccess) return (size_t)8 << 30;
+  return f;
+}
+
+template <typename T>
+int nll_impl(gpc_ctx* c, Batch& b, int want_grad, const double* dm, int mean_N, const double* dsn2,
+             int noise_N, double* nlz, double* dnlz, double* sn2_mult, int* L_chol, int* info) {
+  const int S = b.S, npad = b.npad, N = b.N;
+  const size_t per = 3ull * npad * npad * sizeof(T);
+  size_t budget = free_device_bytes() + c->mA.bytes + c->mW.bytes + c->mT.bytes;
+  budget = (size_t)(budget * 0.8);
+  int chunk = (int)std::max<size_t>(1, std::min<size_t>(S, budget / per));
+  HIPCHK(c, c->mA.ensure((size_t)chunk * npad * npad * sizeof(T)));
+  HIPCHK(c, c->mW.ensure((size_t)chunk * npad * npad * sizeof(T)));
+  HIPCHK(c, c->mT.ensure((size_t)chunk * npad * npad * sizeof(T)));
+
+  Pipe<T> p;
+  p.c = c;
+  p.B = &b;
+  p.mode = want_grad ? MODE_GRAD : MODE_NLL;
+  p.A = c->mA.as<T>();
+  p.W = c->mW.as<T>();
+  p.Tm = c->mT.as<T>();
+  p.sM = (long long)npad * npad;
+  p.dm = dm;
+  p.mean_N = mean_N;
+  p.dsn2 = dsn2;
+  p.noise_N = noise_N;
+  const int Pn = p.P();
+  p.logdet.assign(S, 0.0);
+  p.quad.assign(S, 0.0);
+  p.G.assign((size_t)S * Pn, 0.0);
+  p.mg.assign((size_t)S * std::max(mean_N, 1), 0.0);
+  p.ng.assign((size_t)S * std::max(noise_N, 1), 0.0);
+
+  c->ms_total = c->ms_factor = 0;
+  c->last_flops = 0;
+  for (int s0 = 0; s0 < S; s0 += chunk) {
+    const int cnt = std::min(chunk, S - s0);
+    int rc = p.run(s0, cnt, 0);
+    if (rc) return rc;
+    for (int s = s0; s < s0 + cnt; ++s)
+      if (b.info[s] != 0) {
+        rc = p.retry(s, 0);
+        if (rc) return rc;
+      }
+  }
+  const int cov_N = b.cd.cov_N;
+  const int hyp_N = cov_N + noise_N + mean_N;
+  for (int s = 0; s < S; ++s) {
+    const double sl = b.sl[s];
+    nlz[s] = 0.5 * p.quad[s] / sl + p.logdet[s] + N * std::log(2 * M_PI * sl) / 2;
+    sn2_mult[s] = b.mult[s];
+    L_chol[s] = b.lchol[s];
+    info[s] = b.info[s];
+    if (want_grad) {
+      double* g = dnlz + (size_t)s * hyp_N;
+      for (int h = 0; h < cov_N; ++h) g[h] = p.G[(size_t)s * Pn + h] / 2;  // :2487-2488
+      const double trQ = p.G[(size_t)s * Pn + cov_N];
+      for (int i = 0; i < noise_N; ++i) {
+        if (b.vec_noise)
+          g[cov_N + i] = 0.5 * b.mult[s] * p.ng[(size_t)s * noise_N + i];  // :2500-2504
+        else
+          g[cov_N + i] = 0.5 * b.mult[s] * dsn2[(size_t)s * noise_N + i] * trQ;  // :2491-2498
+      }
+      for (int i = 0; i < mean_N; ++i) g[cov_N + noise_N + i] = -p.mg[(size_t)s * mean_N + i];  // :2507-2508
+    }
+  }
+  return 0;
+}
+
+int check_batch_args(gpc_ctx* c, int kernel_id, int degree, int dtype, int S) {
+  if (!c) return -2;
+  if (c->N <= 0) FAIL(c, "gpc_set_data has not been called");
+  if (!valid_kernel(kernel_id, degree)) FAIL(c, "unknown covariance kernel / degree");
+  if (dtype != GPC_F64 && dtype != GPC_F32) FAIL(c, "dtype must be GPC_F64 or GPC_F32");
+  if (S <= 0) FAIL(c, "S must be positive");
+  return 0;
+}
+
+void fill_batch(gpc_ctx* c, Batch& b, int kernel_id, int degree, int S, const double* hyp_cov,
+                const double* m, const double* sn2, int vec) {
+  b.S = S;
+  b.N = c->N;
+  b.D = c->D;
+  b.npad = c->npad;
+  b.cd.kind = kernel_id;
+  b.cd.degree = degree;
+  b.cd.D = c->D;
+  b.cd.cov_N = cov_count_of(kernel_id, c->D);
+  b.vec_noise = vec != 0;
+  b.hyp_cov = hyp_cov;
+  b.m = m;
+  b.sn2 = sn2;
+  b.y = c->hy.data();
+  b.init();
+}
+
+template <typename T>
+int post_impl(gpc_ctx* c, Batch& b, gpc_post* po, double* sn2_mult, int* L_chol, int* info) {
+  const int S = b.S, npad = b.npad;
+  const size_t msz = (size_t)npad * npad * sizeof(T);
+  HIPCHK(c, po->A.ensure(S * msz));
+  HIPCHK(c, po->W.ensure(S * msz));
+  HIPCHK(c, po->alpha.ensure((size_t)S * npad * sizeof(double)));
+  size_t budget = (size_t)((free_device_bytes() + c->mT.bytes) * 0.8);
+  int chunk = (int)std::max<size_t>(1, std::min<size_t>(S, budget / msz));
+  HIPCHK(c, c->mT.ensure((size_t)chunk * msz));
+
+  Pipe<T> p;
+  p.c = c;
+  p.B = &b;
+  p.mode = MODE_POST;
+  p.sM = (long long)npad * npad;
+  p.logdet.assign(S, 0.0);
+  p.quad.assign(S, 0.0);
+  c->ms_total = c->ms_factor = 0;
+  c->last_flops = 0;
+  for (int s0 = 0; s0 < S; s0 += chunk) {
+    const int cnt = std::min(chunk, S - s0);
+    // matrices of sample s live at po->A + s*sM; the pipe indexes from `slot`
+    p.A = po->A.as<T>() + (size_t)s0 * p.sM;
+    p.W = po->W.as<T>() + (size_t)s0 * p.sM;
+    p.Tm = c->mT.as<T>();
+    int rc = p.run(s0, cnt, 0);
+    if (rc) return rc;
+    auto save_alpha = [&](int s, int src_slot) -> int {
+      HIPCHK(c, hipMemcpyAsync(po->alpha.as<double>() + (size_t)s * npad,
+                               c->avec.as<double>() + (size_t)src_slot * npad, npad * sizeof(double),
+                               hipMemcpyDeviceToDevice, c->st));
+      return 0;
+    };
+    for (int i = 0; i < cnt; ++i)
+      if (b.info[s0 + i] == 0 && save_alpha(s0 + i, i)) return -1;
+    for (int s = s0; s < s0 + cnt; ++s)
+      if (b.info[s] != 0) {
+        p.A = po->A.as<T>() + (size_t)s * p.sM;
+        p.W = po->W.as<T>() + (size_t)s * p.sM;
+        rc = p.retry(s, 0);
+        if (rc) return rc;
+        if (b.info[s] == 0 && save_alpha(s, 0)) return -1;
+      }
+    // low-noise samples: Posterior.L = -(K + mult*Sigma)^-1  (gaussian_process.py:2441-2448)
+    for (int s = s0; s < s0 + cnt; ++s)
+      if (!b.lchol[s] && b.info[s] == 0) {
+        Factor<T> F;
+        F.st = c->st;
+        F.batch = 1;
+        F.npad = npad;
+        F.A = po->A.as<T>() + (size_t)s * p.sM;
+        F.W = po->W.as<T>() + (size_t)s * p.sM;
+        F.Tm = c->mT.as<T>();
+        F.sA = F.sW = F.sT = p.sM;
+        F.lauum(F.Tm, p.sM);
+        HIPCHK(c, F.err);
+        dim3 g1(npad / 64, npad / 4, 1), blk(64, 4);
+        hipLaunchKernelGGL((neg_sym_kernel<T>), g1, blk, 0, c->st, F.Tm, p.sM, npad, npad);
+        HIPCHK(c, hipMemcpyAsync(F.A, F.Tm, msz, hipMemcpyDeviceToDevice, c->st));
+        HIPCHK(c, hipGetLastError());
+      }
+    HIPCHK(c, hipStreamSynchronize(c->st));
+  }
+  po->sp = b.sp;
+  po->mul = b.mul;
+  po->dv = b.dv;
+  po->mult = b.mult;
+  po->lchol = b.lchol;
+  po->info = b.info;
+  po->sW.resize(S);
+  for (int s = 0; s < S; ++s) {
+    po->sW[s] = 1.0 / std::sqrt(b.smin[s] * b.mult[s]);  // :2517
+    sn2_mult[s] = b.mult[s];
+    L_chol[s] = b.lchol[s];
+    info[s] = b.info[s];
+  }
+  return 0;
+}
+
+template <typename T>
+int predict_impl(gpc_post* po, const double* xstar, int M, double* fmu, double* fs2) {
+  gpc_ctx* c = po->ctx;
+  const int S = po->S, N = po->N, D = po->D, npad = po->npad;
+  const int mpad = pad_tile(M);
+  hipStream_t st = c->st;
+  const long long sM = (long long)npad * npad;
+  const long long sKs = (long long)npad * mpad;
+  // chunk over samples so that Ks and V fit comfortably
+  const size_t per = 2ull * npad * mpad * sizeof(T);
+  size_t budget = (size_t)((free_device_bytes() + c->ks.bytes + c->vb.bytes) * 0.8);
+  int chunk = (int)std::max<size_t>(1, std::min<size_t>(S, budget / per));
+  HIPCHK(c, c->ks.ensure((size_t)chunk * sKs * sizeof(T)));
+  HIPCHK(c, c->vb.ensure((size_t)chunk * sKs * sizeof(T)));
+  HIPCHK(c, c->xss.ensure(((size_t)chunk * mpad * D + (size_t)M * D) * 8));
+  HIPCHK(c, c->xs.ensure((size_t)chunk * npad * D * 8));
+  HIPCHK(c, c->spb.ensure((size_t)chunk * SP_STRIDE * 8));
+  HIPCHK(c, c->mulb.ensure((size_t)chunk * D * 8));
+  HIPCHK(c, c->divb.ensure((size_t)chunk * D * 8));
+  HIPCHK(c, c->pout.ensure((size_t)chunk * mpad * 2 * 8));
+  double* d_xraw = c->xss.as<double>() + (size_t)chunk * mpad * D;
+  HIPCHK(c, hipMemcpyAsync(d_xraw, xstar, (size_t)M * D * 8, hipMemcpyHostToDevice, st));
+  std::vector<double> hmu((size_t)chunk * mpad), hv((size_t)chunk * mpad);
+
+  for (int s0 = 0; s0 < S; s0 += chunk) {
+    const int cnt = std::min(chunk, S - s0);
+    HIPCHK(c, hipMemcpyAsync(c->spb.p, &po->sp[(size_t)s0 * SP_STRIDE], (size_t)cnt * SP_STRIDE * 8,
+                             hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->mulb.p, &po->mul[(size_t)s0 * D], (size_t)cnt * D * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->divb.p, &po->dv[(size_t)s0 * D], (size_t)cnt * D * 8, hipMemcpyHostToDevice, st));
+    {
+      long long tot = (long long)npad * D;
+      hipLaunchKernelGGL(scale_x_kernel, dim3((unsigned)((tot + 255) / 256), cnt), dim3(256), 0, st,
+                         c->dX.as<double>(), N, npad, D, c->mulb.as<double>(), c->divb.as<double>(),
+                         c->xs.as<double>());
+      tot = (long long)mpad * D;
+      hipLaunchKernelGGL(scale_x_kernel, dim3((unsigned)((tot + 255) / 256), cnt), dim3(256), 0, st,
+                         (const double*)d_xraw, M, mpad, D, c->mulb.as<double>(), c->divb.as<double>(),
+                         c->xss.as<double>());
+    }
+    T* Ks = c->ks.as<T>();
+    T* V = c->vb.as<T>();
+    hipLaunchKernelGGL((cross_kernel<T>), dim3(mpad / 64, npad / 4, cnt), dim3(64, 4), 0, st, po->cd,
+                       c->xs.as<double>(), c->xss.as<double>(), c->spb.as<double>(), N, npad, M, mpad, Ks, sKs);
+    // fmu = Ks^T alpha
+    double* d_mu = c->pout.as<double>();
+    double* d_v = d_mu + (size_t)chunk * mpad;
+    hipLaunchKernelGGL((colsum_vec_kernel<T>), dim3(mpad / 64, cnt), dim3(256), 0, st, (const T*)Ks, sKs, mpad,
+                       po->alpha.as<double>() + (size_t)s0 * npad, npad, npad, mpad, d_mu);
+    HIPCHK(c, hipGetLastError());
+    // runs of equal L_chol share launches
+    int a = 0;
+    while (a < cnt) {
+      int e = a;
+      while (e < cnt && po->lchol[s0 + e] == po->lchol[s0 + a]) ++e;
+      const int len = e - a;
+      GemmArgs g;
+      g.B = Ks + (size_t)a * sKs;
+      g.C = V + (size_t)a * sKs;
+      g.sB = g.sC = sKs;
+      g.sA = sM;
+      g.lda = npad;
+      g.ldb = g.ldc = mpad;
+      g.M = npad;
+      g.N = mpad;
+      g.K = npad;
+      g.alpha = 1.0;
+      g.beta = 0;
+      g.klo = KLO_ZERO;
+      g.lower_only = 0;
+      g.tiles_n = mpad / TILE;
+      if (po->lchol[s0 + a]) {
+        g.A = po->W.as<T>() + (size_t)(s0 + a) * sM;  // V = W Ks  (k <= row tile)
+        g.khi = KHI_ROW;
+        HIPCHK(c, launch_gemm<T>(st, g, false, true, len));
+        hipLaunchKernelGGL((colsum_prod_kernel<T>), dim3(mpad / 64, len), dim3(256), 0, st,
+                           (const T*)(V + (size_t)a * sKs), sKs, (const T*)(V + (size_t)a * sKs), sKs, mpad,
+                           npad, mpad, d_v + (size_t)a * mpad);
+      } else {
+        g.A = po->A.as<T>() + (size_t)(s0 + a) * sM;  // G = L Ks with L = -inv (full symmetric)
+        g.khi = KHI_FULL;
+        HIPCHK(c, launch_gemm<T>(st, g, false, true, len));
+        hipLaunchKernelGGL((colsum_prod_kernel<T>), dim3(mpad / 64, len), dim3(256), 0, st,
+                           (const T*)(Ks + (size_t)a * sKs), sKs, (const T*)(V + (size_t)a * sKs), sKs, mpad,
+                           npad, mpad, d_v + (size_t)a * mpad);
+      }
+      a = e;
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(hmu.data(), d_mu, (size_t)cnt * mpad * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(hv.data(), d_v, (size_t)cnt * mpad * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    for (int i = 0; i < cnt; ++i) {
+      const int s = s0 + i;
+      const double sf2 = po->sp[(size_t)s * SP_STRIDE + SP_SF2];
+      const double sl = po->sp[(size_t)s * SP_STRIDE + SP_SL];
+      for (int j = 0; j < M; ++j) {
+        fmu[(size_t)j * S + s] = hmu[(size_t)i * mpad + j];
+        const double q = hv[(size_t)i * mpad + j];
+        // L_chol: kss - sum(V*V), V = sW * (W Ks), sW^2 = 1/sl   (:1752-1760)
+        // else  : kss + sum(Ks * (L Ks))                          (:1762-1764)
+        fs2[(size_t)j * S + s] = po->lchol[s] ? sf2 - q / sl : sf2 + q;
+      }
+    }
+  }
+  return 0;
+}
+
+}  // namespace
+
+// test-hook helpers
+namespace {
+template <typename T>
+int upload_as(gpc_ctx* c, DevBuf& buf, const double* src, size_t n) {
+  HIPCHK(c, buf.ensure(n * sizeof(T)));
+  if constexpr (sizeof(T) == 8) {
+    HIPCHK(c, hipMemcpyAsync(buf.p, src, n * 8, hipMemcpyHostToDevice, c->st));
+  } else {
+    std::vector<float> tmp(n);
+    for (size_t i = 0; i < n; ++i) tmp[i] = (float)src[i];
+    HIPCHK(c, hipMemcpyAsync(buf.p, tmp.data(), n * 4, hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+  }
+  return 0;
+}
+template <typename T>
+int download_as(gpc_ctx* c, const T* src, double* dst, size_t n) {
+  if constexpr (sizeof(T) == 8) {
+    HIPCHK(c, hipMemcpyAsync(dst, src, n * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+  } else {
+    std::vector<float> tmp(n);
+    HIPCHK(c, hipMemcpyAsync(tmp.data(), src, n * 4, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    for (size_t i = 0; i < n; ++i) dst[i] = tmp[i];
+  }
+  return 0;
+}
+
+template <typename T>
+int debug_gemm_impl(gpc_ctx* c, int M, int N, int K, int akm, int bkm, double alpha, int beta, int klo,
+                    int khi, int lower, const double* A, const double* B, double* C) {
+  if (upload_as<T>(c, c->dbg1, A, (size_t)M * K)) return -1;
+  if (upload_as<T>(c, c->dbg2, B, (size_t)N * K)) return -1;
+  if (upload_as<T>(c, c->dbg3, C, (size_t)M * N)) return -1;
+  GemmArgs g;
+  g.A = c->dbg1.p;
+  g.B = c->dbg2.p;
+  g.C = c->dbg3.p;
+  g.sA = g.sB = g.sC = 0;
+  g.lda = akm ? M : K;
+  g.ldb = bkm ? N : K;
+  g.ldc = N;
+  g.M = M;
+  g.N = N;
+  g.K = K;
+  g.alpha = alpha;
+  g.beta = beta;
+  g.klo = klo;
+  g.khi = khi;
+  g.lower_only = lower;
+  g.tiles_n = N / TILE;
+  HIPCHK(c, launch_gemm<T>(c->st, g, akm != 0, bkm != 0, 1));
+  return download_as<T>(c, c->dbg3.as<T>(), C, (size_t)M * N);
+}
+
+template <typename T>
+int debug_factor_impl(gpc_ctx* c, int n, const double* A, double* L, double* W, double* Ainv,
+                      double* logdet, int* info) {
+  const int npad = pad_tile(n);
+  const size_t msz = (size_t)npad * npad;
+  HIPCHK(c, c->mA.ensure(msz * sizeof(T)));
+  HIPCHK(c, c->mW.ensure(msz * sizeof(T)));
+  HIPCHK(c, c->mT.ensure(msz * sizeof(T)));
+  HIPCHK(c, c->dbg1.ensure((size_t)n * n * 8));
+  HIPCHK(c, c->scal.ensure(64));
+  HIPCHK(c, hipMemcpyAsync(c->dbg1.p, A, (size_t)n * n * 8, hipMemcpyHostToDevice, c->st));
+  HIPCHK(c, hipMemsetAsync(c->scal.p, 0, 64, c->st));
+  dim3 blk(64, 4), gp(npad / 64, npad / 4);
+  hipLaunchKernelGGL((pad_load_kernel<T>), gp, blk, 0, c->st, c->dbg1.as<double>(), n, npad, c->mA.as<T>());
+  Factor<T> F;
+  F.st = c->st;
+  F.batch = 1;
+  F.npad = npad;
+  F.A = c->mA.as<T>();
+  F.W = c->mW.as<T>();
+  F.Tm = c->mT.as<T>();
+  F.sA = F.sW = F.sT = (long long)msz;
+  F.logdet = c->scal.as<double>();
+  F.info = reinterpret_cast<int*>(c->scal.as<double>() + 1);
+  F.potrf_inv(0, npad, true, true);
+  HIPCHK(c, F.err);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, c->dbg3.ensure((size_t)n * n * 8));
+  dim3 gn((n + 63) / 64, (n + 3) / 4);
+  if (L) {
+    hipLaunchKernelGGL((extract_kernel<T>), gn, blk, 0, c->st, (const T*)F.A, npad, n, 0, c->dbg3.as<double>());
+    HIPCHK(c, hipMemcpyAsync(L, c->dbg3.p, (size_t)n * n * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+  }
+  if (W) {
+    hipLaunchKernelGGL((extract_kernel<T>), gn, blk, 0, c->st, (const T*)F.W, npad, n, 0, c->dbg3.as<double>());
+    HIPCHK(c, hipMemcpyAsync(W, c->dbg3.p, (size_t)n * n * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+  }
+  if (Ainv) {
+    F.lauum(F.Tm, F.sT);
+    HIPCHK(c, F.err);
+    hipLaunchKernelGGL((extract_kernel<T>), gn, blk, 0, c->st, (const T*)F.Tm, npad, n, 0, c->dbg3.as<double>());
+    HIPCHK(c, hipMemcpyAsync(Ainv, c->dbg3.p, (size_t)n * n * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+  }
+  double h[2];
+  HIPCHK(c, hipMemcpyAsync(h, c->scal.p, 16, hipMemcpyDeviceToHost, c->st));
+  HIPCHK(c, hipStreamSynchronize(c->st));
+  if (logdet) *logdet = h[0];
+  if (info) memcpy(info, &h[1], sizeof(int));
+  return 0;
+}
+}  // namespace
+
+// =====================================================================================
+// C ABI
+// =====================================================================================
+extern "C" {
+
+int gpc_create(int device, gpc_ctx** out) {
+  if (!out) return -2;
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    g_create_err = std::string("no HIP device: ") + hipGetErrorString(e);
+    return -1;
+  }
+  if (device < 0 || device >= count) {
+    g_create_err = "device index out of range";
+    return -2;
+  }
+  e = hipSetDevice(device);
+  if (e != hipSuccess) {
+    g_create_err = hipGetErrorString(e);
+    return -1;
+  }
+  gpc_ctx* c = new gpc_ctx();
+  c->device = device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s arch=%s CUs=%d clock=%dMHz mem=%.1fGB lds/block=%zuKB", prop.name,
+             prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1000,
+             prop.totalGlobalMem / 1073741824.0, prop.sharedMemPerBlock / 1024);
+    c->devinfo = buf;
+  }
+  if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess) {
+    g_create_err = "hipStreamCreate failed";
+    delete c;
+    return -1;
+  }
+  for (auto& ev : c->ev)
+    if (hipEventCreate(&ev) != hipSuccess) {
+      g_create_err = "hipEventCreate failed";
+      delete c;
+      return -1;
+    }
+  *out = c;
+  return 0;
+}
+
+void gpc_destroy(gpc_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->st);
+  DevBuf* bufs[] = {&c->dX,   &c->mA,    &c->mW,  &c->mT,   &c->xs,   &c->spb,  &c->mulb, &c->divb,
+                    &c->dvec, &c->rvec,  &c->zvec, &c->avec, &c->scal, &c->parts, &c->gout, &c->diagq,
+                    &c->dmb,  &c->dsn2b, &c->mg,  &c->ng,   &c->ks,   &c->vb,   &c->xss,  &c->pout,
+                    &c->dbg1, &c->dbg2,  &c->dbg3};
+  for (DevBuf* b : bufs) b->release();
+  for (auto& ev : c->ev)
+    if (ev) (void)hipEventDestroy(ev);
+  if (c->st) (void)hipStreamDestroy(c->st);
+  delete c;
+}
+
+const char* gpc_last_error(const gpc_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+const char* gpc_device_info(gpc_ctx* c) { return c ? c->devinfo.c_str() : ""; }
+
+int gpc_cov_count(int kernel_id, int D) { return cov_count_of(kernel_id, D); }
+
+int gpc_set_data(gpc_ctx* c, const double* X, const double* y, int N, int D) {
+  if (!c) return -2;
+  if (!X || !y || N <= 0 || D <= 0) FAIL(c, "gpc_set_data: X, y must be non-null and N, D positive");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, c->dX.ensure((size_t)N * D * sizeof(double)));
+  HIPCHK(c, hipMemcpyAsync(c->dX.p, X, (size_t)N * D * sizeof(double), hipMemcpyHostToDevice, c->st));
+  HIPCHK(c, hipStreamSynchronize(c->st));
+  c->hy.assign(y, y + N);
+  c->N = N;
+  c->D = D;
+  c->npad = pad_tile(N);
+  return 0;
+}
+
+int gpc_kernel(gpc_ctx* c, int kernel_id, int degree, const double* hyp_cov, const double* X, int N, int D,
+               const double* Xstar, int M, int diag, double* K, double* dK) {
+  if (!c) return -2;
+  if (!valid_kernel(kernel_id, degree)) FAIL(c, "unknown covariance kernel / degree");
+  if (!hyp_cov || !X || !K || N <= 0 || D <= 0) FAIL(c, "gpc_kernel: bad arguments");
+  if (Xstar && dK) FAIL(c, "X_star should be None when compute_grad is True.");
+  HIPCHK(c, hipSetDevice(c->device));
+  CovDesc cd{kernel_id, degree, D, cov_count_of(kernel_id, D)};
+  std::vector<double> mul(D), dv(D);
+  double sf2, rqa;
+  scaling_of(kernel_id, degree, D, hyp_cov, mul.data(), dv.data(), &sf2, &rqa);
+  if (diag) {  // zero distance: covariance_functions.py:162-163
+    for (int i = 0; i < N; ++i) K[i] = sf2;
+    return 0;
+  }
+  const int Mc = Xstar ? M : N;
+  if (Mc <= 0) FAIL(c, "gpc_kernel: M must be positive with Xstar");
+  hipStream_t st = c->st;
+  // dbg1: raw X | raw X* | mul | div ; dbg2: scaled Xa | scaled Xb ; dbg3: K | dK
+  const size_t nraw = (size_t)N * D + (size_t)Mc * D + 2 * (size_t)D;
+  HIPCHK(c, c->dbg1.ensure(nraw * 8));
+  HIPCHK(c, c->dbg2.ensure(((size_t)N * D + (size_t)Mc * D) * 8));
+  const size_t nK = (size_t)N * Mc, ndK = dK ? nK * cd.cov_N : 0;
+  HIPCHK(c, c->dbg3.ensure((nK + ndK) * 8));
+  double* d_xa = c->dbg1.as<double>();
+  double* d_xb = d_xa + (size_t)N * D;
+  double* d_mul = d_xb + (size_t)Mc * D;
+  double* d_div = d_mul + D;
+  HIPCHK(c, hipMemcpyAsync(d_xa, X, (size_t)N * D * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(d_xb, Xstar ? Xstar : X, (size_t)Mc * D * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(d_mul, mul.data(), D * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(d_div, dv.data(), D * 8, hipMemcpyHostToDevice, st));
+  double* s_xa = c->dbg2.as<double>();
+  double* s_xb = s_xa + (size_t)N * D;
+  hipLaunchKernelGGL(scale_x_kernel, dim3((unsigned)(((long long)N * D + 255) / 256), 1), dim3(256), 0, st,
+                     (const double*)d_xa, N, N, D, (const double*)d_mul, (const double*)d_div, s_xa);
+  hipLaunchKernelGGL(scale_x_kernel, dim3((unsigned)(((long long)Mc * D + 255) / 256), 1), dim3(256), 0, st,
+                     (const double*)d_xb, Mc, Mc, D, (const double*)d_mul, (const double*)d_div, s_xb);
+  double* d_K = c->dbg3.as<double>();
+  double* d_dK = dK ? d_K + nK : nullptr;
+  hipLaunchKernelGGL(full_cov_kernel, dim3((Mc + 63) / 64, (N + 3) / 4), dim3(64, 4), 0, st, cd,
+                     (const double*)s_xa, (const double*)s_xb, sf2, rqa, N, Mc, d_K, d_dK);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(K, d_K, nK * 8, hipMemcpyDeviceToHost, st));
+  if (dK) HIPCHK(c, hipMemcpyAsync(dK, d_dK, ndK * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  return 0;
+}
+
+int gpc_nll_batch(gpc_ctx* c, int kernel_id, int degree, int dtype, int S, const double* hyp_cov,
+                  const double* m, const double* sn2, int sn2_is_vector, int want_grad, const double* dm,
+                  int mean_N, const double* dsn2, int noise_N, double* nlz, double* dnlz, double* sn2_mult,
+                  int* L_chol, int* info) {
+  int rc = check_batch_args(c, kernel_id, degree, dtype, S);
+  if (rc) return rc;
+  if (!hyp_cov || !m || !sn2 || !nlz || !sn2_mult || !L_chol || !info) FAIL(c, "gpc_nll_batch: null argument");
+  if (want_grad && (!dnlz || (mean_N > 0 && !dm) || (noise_N > 0 && !dsn2)))
+    FAIL(c, "gpc_nll_batch: gradient requested without dnlz/dm/dsn2");
+  HIPCHK(c, hipSetDevice(c->device));
+  Batch b;
+  fill_batch(c, b, kernel_id, degree, S, hyp_cov, m, sn2, sn2_is_vector);
+  if (dtype == GPC_F64)
+    return nll_impl<double>(c, b, want_grad, dm, mean_N, dsn2, noise_N, nlz, dnlz, sn2_mult, L_chol, info);
+  return nll_impl<float>(c, b, want_grad, dm, mean_N, dsn2, noise_N, nlz, dnlz, sn2_mult, L_chol, info);
+}
+
+int gpc_posterior_batch(gpc_ctx* c, int kernel_id, int degree, int dtype, int S, const double* hyp_cov,
+                        const double* m, const double* sn2, int sn2_is_vector, gpc_post** post,
+                        double* sn2_mult, int* L_chol, int* info) {
+  int rc = check_batch_args(c, kernel_id, degree, dtype, S);
+  if (rc) return rc;
+  if (!hyp_cov || !m || !sn2 || !post || !sn2_mult || !L_chol || !info) FAIL(c, "gpc_posterior_batch: null argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  Batch b;
+  fill_batch(c, b, kernel_id, degree, S, hyp_cov, m, sn2, sn2_is_vector);
+  gpc_post* po = new gpc_post();
+  po->ctx = c;
+  po->dtype = dtype;
+  po->S = S;
+  po->N = c->N;
+  po->D = c->D;
+  po->npad = c->npad;
+  po->cd = b.cd;
+  rc = (dtype == GPC_F64) ? post_impl<double>(c, b, po, sn2_mult, L_chol, info)
+                          : post_impl<float>(c, b, po, sn2_mult, L_chol, info);
+  if (rc) {
+    po->A.release();
+    po->W.release();
+    po->alpha.release();
+    delete po;
+    return rc;
+  }
+  *post = po;
+  return 0;
+}
+
+int gpc_post_fetch(gpc_post* po, int s, double* alpha, double* sW, double* L) {
+  if (!po) return -2;
+  gpc_ctx* c = po->ctx;
+  if (s < 0 || s >= po->S) FAIL(c, "gpc_post_fetch: sample index out of range");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int N = po->N, npad = po->npad;
+  if (alpha) {
+    HIPCHK(c, hipMemcpyAsync(alpha, po->alpha.as<double>() + (size_t)s * npad, N * sizeof(double),
+                             hipMemcpyDeviceToHost, c->st));
+  }
+  if (sW)
+    for (int i = 0; i < N; ++i) sW[i] = po->sW[s];
+  if (L) {
+    HIPCHK(c, c->dbg3.ensure((size_t)N * N * 8));
+    dim3 grid((N + 63) / 64, (N + 3) / 4), blk(64, 4);
+    const int mode = po->lchol[s] ? 0 : 2;  // low-noise: A already holds the full -inv
+    if (po->dtype == GPC_F64)
+      hipLaunchKernelGGL((extract_kernel<double>), grid, blk, 0, c->st,
+                         (const double*)(po->A.as<double>() + (size_t)s * npad * npad), npad, N, mode,
+                         c->dbg3.as<double>());
+    else
+      hipLaunchKernelGGL((extract_kernel<float>), grid, blk, 0, c->st,
+                         (const float*)(po->A.as<float>() + (size_t)s * npad * npad), npad, N, mode,
+                         c->dbg3.as<double>());
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(L, c->dbg3.p, (size_t)N * N * 8, hipMemcpyDeviceToHost, c->st));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->st));
+  return 0;
+}
+
+int gpc_post_free(gpc_post* po) {
+  if (!po) return 0;
+  (void)hipSetDevice(po->ctx->device);
+  (void)hipStreamSynchronize(po->ctx->st);
+  po->A.release();
+  po->W.release();
+  po->alpha.release();
+  delete po;
+  return 0;
+}
+
+int gpc_predict(gpc_post* po, const double* xstar, int M, double* fmu, double* fs2) {
+  if (!po) return -2;
+  gpc_ctx* c = po->ctx;
+  if (!xstar || !fmu || !fs2 || M <= 0) FAIL(c, "gpc_predict: bad arguments");
+  for (int s = 0; s < po->S; ++s)
+    if (po->info[s] != 0) FAIL(c, "gpc_predict: posterior contains a failed factorization");
+  HIPCHK(c, hipSetDevice(c->device));
+  return po->dtype == GPC_F64 ? predict_impl<double>(po, xstar, M, fmu, fs2)
+                              : predict_impl<float>(po, xstar, M, fmu, fs2);
+}
+
+int gpc_last_timing(gpc_ctx* c, double* ms_total, double* ms_factor) {
+  if (!c) return -2;
+  if (ms_total) *ms_total = c->ms_total;
+  if (ms_factor) *ms_factor = c->ms_factor;
+  return 0;
+}
+
+int gpc_mfma_peak(gpc_ctx* c, int dtype, double* tflops, double* cycles_per_mfma, double* clock_ghz) {
+  if (!c || !tflops) return -2;
+  HIPCHK(c, hipSetDevice(c->device));
+  hipDeviceProp_t prop;
+  HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
+  const int blocks = prop.multiProcessorCount * 2;  // 8 waves per CU = 2 per SIMD
+  const int iters = 4096;
+  HIPCHK(c, c->dbg1.ensure((size_t)blocks * 256 * 8));
+  HIPCHK(c, c->dbg2.ensure(64));
+  long long* d_clk = c->dbg2.as<long long>();
+  auto launch = [&]() {
+    if (dtype == GPC_F64)
+      hipLaunchKernelGGL((mfma_peak_kernel<double>), dim3(blocks), dim3(256), 0, c->st, c->dbg1.as<double>(), iters, d_clk);
+    else
+      hipLaunchKernelGGL((mfma_peak_kernel<float>), dim3(blocks), dim3(256), 0, c->st, c->dbg1.as<float>(), iters, d_clk);
+  };
+  launch();
+  HIPCHK(c, hipStreamSynchronize(c->st));
+  HIPCHK(c, hipEventRecord(c->ev[0], c->st));
+  const int reps = 5;
+  for (int r = 0; r < reps; ++r) launch();
+  HIPCHK(c, hipEventRecord(c->ev[1], c->st));
+  HIPCHK(c, hipStreamSynchronize(c->st));
+  float ms = 0;
+  HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+  const double flops = (double)reps * blocks * 4.0 /*waves*/ * iters * 8.0 * (2.0 * 16 * 16 * 4);
+  *tflops = flops / (ms * 1e-3) / 1e12;
+  long long hclk[2] = {0, 0};
+  HIPCHK(c, hipMemcpy(hclk, d_clk, sizeof hclk, hipMemcpyDeviceToHost));
+  if (cycles_per_mfma) *cycles_per_mfma = (double)hclk[0] / ((double)iters * 8.0) / 2.0;  // 2 waves share a SIMD
+  if (clock_ghz) *clock_ghz = hclk[1] > 0 ? (double)hclk[0] / ((double)hclk[1] * 10.0) / 1.0 : 0.0;  // cycles per ns
+  return 0;
+}
+
+// ------------------------------- test hooks ------------------------------------------
+
+int gpc_debug_gemm(gpc_ctx* c, int dtype, int M, int N, int K, int a_kmajor, int b_kmajor, double alpha,
+                   int beta, int klo, int khi, int lower_only, const double* A, const double* B, double* C) {
+  if (!c) return -2;
+  if (M % TILE || N % TILE || K % TILE || M <= 0 || N <= 0 || K <= 0) FAIL(c, "gpc_debug_gemm: sizes must be multiples of 128");
+  if (lower_only && M != N) FAIL(c, "gpc_debug_gemm: lower_only needs M == N");
+  HIPCHK(c, hipSetDevice(c->device));
+  return dtype == GPC_F64
+             ? debug_gemm_impl<double>(c, M, N, K, a_kmajor, b_kmajor, alpha, beta, klo, khi, lower_only, A, B, C)
+             : debug_gemm_impl<float>(c, M, N, K, a_kmajor, b_kmajor, alpha, beta, klo, khi, lower_only, A, B, C);
+}
+
+int gpc_debug_leaf(gpc_ctx* c, int dtype, const double* A, double* L, double* W, double* logdet, int* info) {
+  return gpc_debug_factor(c, dtype, TILE, A, L, W, nullptr, logdet, info);
+}
+
+int gpc_debug_factor(gpc_ctx* c, int dtype, int n, const double* A, double* L, double* W, double* Ainv,
+                     double* logdet, int* info) {
+  if (!c) return -2;
+  if (!A || n <= 0) FAIL(c, "gpc_debug_factor: bad arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  return dtype == GPC_F64 ? debug_factor_impl<double>(c, n, A, L, W, Ainv, logdet, info)
+                          : debug_factor_impl<float>(c, n, A, L, W, Ainv, logdet, info);
+}
+
+}  // extern "C"

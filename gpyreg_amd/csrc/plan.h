@@ -1,0 +1,107 @@
+// plan.h -- host-side launch plan of the blocked factorization (batched over samples).
+//
+//   potrf_inv : A = L L^T  and  W = L^-1   (recursive; every product is gemm.h, the
+//               128 x 128 diagonal blocks are leaf.h)
+//   lauum     : Ainv = W^T W               (one triangular-aware GEMM launch)
+//
+// The recursion (verified on the CPU by tests/blocked_model.py, which executes this
+// same plan with NumPy tiles) on a diagonal block split [n1 | n2]:
+//   1. potrf_inv(A11)                      -> L11, W11
+//   2. T21 = A21 * W11^T                   (the trsm, as a product; k <= column tile)
+//   3. A22 -= T21 * T21^T                  (syrk, lower tiles)
+//   4. potrf_inv(A22)                      -> L22, W22
+//   5. U = T21 * W11 (into A21);  W21 = -W22 * U      (only if this block's inverse is needed)
+//   6. A21 = T21                           (only where L21 must survive)
+// Buffers: A (in: SPD lower; out: L), W (out), T (scratch; receives Ainv).  No launch
+// aliases its output with an input.  Strictly-upper tiles of A, W, T are never read.
+#pragma once
+#include "blas1.h"
+#include "gemm.h"
+#include "leaf.h"
+
+namespace gpc {
+
+template <typename T>
+struct Factor {
+  hipStream_t st;
+  int batch;
+  int npad;
+  T* A;
+  T* W;
+  T* Tm;
+  long long sA, sW, sT;  // batch strides (elements)
+  double* logdet;        // [batch], must be zeroed by the caller
+  int* info;             // [batch], must be zeroed by the caller
+  double flops = 0;      // algorithmic flops issued (tile-exact)
+  int launches = 0;
+  hipError_t err = hipSuccess;
+
+  T* blk(T* base, int r, int c) const { return base + (size_t)r * npad + c; }
+
+  void gemm(T* C, long long sC, const T* Aop, long long sAop, const T* Bop, long long sBop, int M,
+            int N, int K, bool akm, bool bkm, double alpha, int beta, int klo, int khi, int lower) {
+    GemmArgs g;
+    g.A = Aop;
+    g.B = Bop;
+    g.C = C;
+    g.sA = sAop;
+    g.sB = sBop;
+    g.sC = sC;
+    g.lda = g.ldb = g.ldc = npad;
+    g.M = M;
+    g.N = N;
+    g.K = K;
+    g.alpha = alpha;
+    g.beta = beta;
+    g.klo = klo;
+    g.khi = khi;
+    g.lower_only = lower;
+    g.tiles_n = N / TILE;
+    flops += gemm_flops(g, batch);
+    ++launches;
+    hipError_t e = launch_gemm<T>(st, g, akm, bkm, batch);
+    if (e != hipSuccess && err == hipSuccess) err = e;
+  }
+
+  void potrf_inv(int off, int n, bool need_inv, bool keep_L) {
+    if (n == TILE) {
+      hipLaunchKernelGGL((leaf_kernel<T>), dim3(batch), dim3(256), 0, st, blk(A, off, off), sA, npad,
+                         blk(W, off, off), sW, npad, off, logdet, info);
+      flops += (2.0 / 3.0) * TILE * (double)TILE * TILE * batch;
+      ++launches;
+      return;
+    }
+    const int q = n / TILE;
+    const int n1 = (q / 2) * TILE, n2 = n - n1;
+    const int o1 = off, o2 = off + n1;
+    potrf_inv(o1, n1, true, keep_L);
+    // 2. T21 = A21 * W11^T
+    gemm(blk(Tm, o2, o1), sT, blk(A, o2, o1), sA, blk(W, o1, o1), sW, n2, n1, n1, false, false, 1.0,
+         0, KLO_ZERO, KHI_COL, 0);
+    // 3. A22 -= T21 * T21^T
+    gemm(blk(A, o2, o2), sA, blk(Tm, o2, o1), sT, blk(Tm, o2, o1), sT, n2, n2, n1, false, false, -1.0,
+         1, KLO_ZERO, KHI_FULL, 1);
+    potrf_inv(o2, n2, need_inv, keep_L);
+    if (need_inv) {
+      // 5a. U = T21 * W11  -> A21
+      gemm(blk(A, o2, o1), sA, blk(Tm, o2, o1), sT, blk(W, o1, o1), sW, n2, n1, n1, false, true, 1.0,
+           0, KLO_COL, KHI_FULL, 0);
+      // 5b. W21 = -W22 * U
+      gemm(blk(W, o2, o1), sW, blk(W, o2, o2), sW, blk(A, o2, o1), sA, n2, n1, n2, false, true, -1.0,
+           0, KLO_ZERO, KHI_ROW, 0);
+    }
+    if (keep_L || !need_inv) {
+      dim3 grid(n1 / 64, n2 / 4, batch), block(64, 4);
+      hipLaunchKernelGGL((rect_copy_kernel<T>), grid, block, 0, st, (const T*)blk(Tm, o2, o1), sT, npad,
+                         blk(A, o2, o1), sA, npad, n2, n1);
+      ++launches;
+    }
+  }
+
+  // Ainv (lower tiles, into `out`) = W^T W
+  void lauum(T* out, long long sOut) {
+    gemm(out, sOut, W, sW, W, sW, npad, npad, npad, true, true, 1.0, 0, KLO_ROW, KHI_FULL, 1);
+  }
+};
+
+}  // namespace gpc

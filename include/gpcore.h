@@ -1,0 +1,130 @@
+/*
+ * gpcore.h -- C ABI of libgpcore.so, the MI355X (gfx950) dense Gaussian-process core.
+ *
+ * The reference (acerbilab/gpyreg) is pure Python and has no FFI; its boundary for
+ * this path is the duck-typed plugin protocol GP.__init__(D, covariance, mean, noise)
+ * (gaussian_process.py:43-49).  The entry points below are what a ctypes binding on
+ * the reference side would call in place of the NumPy/SciPy bodies cited per function
+ * (see INTEGRATION.md for the stub).  Plain pointers and sizes only; all arrays are
+ * caller-owned host memory, row-major (C order) float64 unless stated; the library
+ * copies inputs to the device and copies results back before returning.
+ *
+ * Return value: 0 = OK; <0 = usage or HIP error (text via gpc_last_error);
+ * per-sample numerical failure is reported in info[] (>0), never as a return code.
+ *
+ * Thread-safety: one gpc_ctx per host thread / per device; calls on one ctx serialize.
+ */
+#ifndef GPCORE_H
+#define GPCORE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gpc_ctx gpc_ctx;   /* one per (process, device): streams, workspace, X, y */
+typedef struct gpc_post gpc_post; /* device-resident posteriors of one hyp batch        */
+
+/* covariance families: covariance_functions.py:131 (SE), :189 (Matern), :288 (RQ-ARD),
+ * isotropic_covariance_functions.py:164 (SE iso), :86 (Matern iso). */
+enum { GPC_K_SE = 0, GPC_K_MATERN = 1, GPC_K_RQ = 2, GPC_K_SE_ISO = 3, GPC_K_MATERN_ISO = 4 };
+/* arithmetic type of the factorization (kernel build and reductions are always f64) */
+enum { GPC_F64 = 0, GPC_F32 = 1 };
+
+/* ---- lifetime ---------------------------------------------------------------- */
+int gpc_create(int device, gpc_ctx** out);
+void gpc_destroy(gpc_ctx* ctx);
+/* last error text of ctx (or of the failed gpc_create when ctx == NULL) */
+const char* gpc_last_error(const gpc_ctx* ctx);
+/* "gfx950 ..." style description of the device and library build */
+const char* gpc_device_info(gpc_ctx* ctx);
+
+/* ---- training data (GP.update stores X, y: gaussian_process.py:846-862) -------- */
+/* X: N x D, y: N.  Kept resident in HBM until the next gpc_set_data. */
+int gpc_set_data(gpc_ctx* ctx, const double* X, const double* y, int N, int D);
+
+/* number of covariance hyperparameters (covariance_functions.py:59-73, :291-292;
+ * isotropic_covariance_functions.py:14-28) */
+int gpc_cov_count(int kernel_id, int D);
+
+/* ---- covariance.compute() (covariance_functions.py:135-186, :221-285, :301-367;
+ *      isotropic_covariance_functions.py:104-161, :173-221) ------------------------
+ * Xstar == NULL, diag == 0 : K is N x N; if dK != NULL it receives N x N x cov_N.
+ * Xstar != NULL            : K is N x M (cross covariance), dK must be NULL.
+ * diag != 0                : K is N (x1): the self-covariance diagonal.            */
+int gpc_kernel(gpc_ctx* ctx, int kernel_id, int degree, const double* hyp_cov,
+               const double* X, int N, int D, const double* Xstar, int M, int diag,
+               double* K, double* dK);
+
+/* ---- GP.__core_computation(hyp, 1, want_grad) for S hyperparameter vectors -------
+ * (gaussian_process.py:2357-2512).  The covariance part runs on the device from
+ * hyp_cov; mean and noise plugins are evaluated by the caller (they are O(N*D)
+ * boundary plugins, mean_functions.py / noise_functions.py) and passed as arrays:
+ *   hyp_cov  S x cov_N
+ *   m        S x N           mean function values
+ *   sn2      S x (sn2_is_vector ? N : 1)   noise variance (noise_functions.py:249-278)
+ *   dm       S x N x mean_N  (want_grad && mean_N > 0, else NULL)
+ *   dsn2     S x (sn2_is_vector ? N : 1) x noise_N (want_grad && noise_N > 0)
+ * Outputs:
+ *   nlz      S               negative log marginal likelihood
+ *   dnlz     S x (cov_N+noise_N+mean_N), order [cov | noise | mean] (:2367-2369)
+ *   sn2_mult S               final jitter multiplier (power of 10, :2413-2421)
+ *   L_chol   S               1 if min(sn2) >= 1e-6 (:2404)
+ *   info     S               0 ok; >0: still not positive definite after 10 tries
+ *                            (the caller raises LinAlgError, :2450-2453)            */
+int gpc_nll_batch(gpc_ctx* ctx, int kernel_id, int degree, int dtype, int S,
+                  const double* hyp_cov, const double* m, const double* sn2,
+                  int sn2_is_vector, int want_grad, const double* dm, int mean_N,
+                  const double* dsn2, int noise_N, double* nlz, double* dnlz,
+                  double* sn2_mult, int* L_chol, int* info);
+
+/* ---- GP.__core_computation(hyp, 0, 0) -> Posterior, for S vectors
+ *      (gaussian_process.py:2514-2521; GP.update loop :870-884) ---------------------
+ * The factors stay in HBM inside *post (freed by gpc_post_free).                   */
+int gpc_posterior_batch(gpc_ctx* ctx, int kernel_id, int degree, int dtype, int S,
+                        const double* hyp_cov, const double* m, const double* sn2,
+                        int sn2_is_vector, gpc_post** post, double* sn2_mult,
+                        int* L_chol, int* info);
+/* Posterior fields of sample s (gaussian_process.py:2568-2586).  Any pointer may be
+ * NULL.  alpha: N.  sW: N.  L: N x N row-major holding, when L_chol, the LOWER
+ * factor Lo with Lo Lo^T = (K + mult*Sigma)/sl -- the reference's upper factor is
+ * its transpose (a free NumPy view) -- else -(K + mult*Sigma)^-1 (:2441-2448).      */
+int gpc_post_fetch(gpc_post* post, int s, double* alpha, double* sW, double* L);
+int gpc_post_free(gpc_post* post);
+
+/* ---- GP.predict K* solves (gaussian_process.py:1741-1764) --------------------------
+ * xstar: M x D.  For every posterior sample s:
+ *   fmu[j*S + s]  = Ks^T alpha                (caller adds the mean function m*)
+ *   fs2[j*S + s]  = kss - colsum(V*V)   or   kss + colsum(Ks * (L Ks))   (unclamped) */
+int gpc_predict(gpc_post* post, const double* xstar, int M, double* fmu, double* fs2);
+
+/* ---- instrumentation -------------------------------------------------------------
+ * GPU time (ms, hipEvent on the library's stream) of the last gpc_nll_batch /
+ * gpc_posterior_batch: whole device section, and the part spent in the MFMA GEMM
+ * launches + leaf factorizations (the N^3 work).                                    */
+int gpc_last_timing(gpc_ctx* ctx, double* ms_total, double* ms_factor);
+/* fp64/fp32 MFMA issue-rate microbenchmark: achieved TFLOP/s of a register-resident
+ * v_mfma_{f64,f32}_16x16x4 loop on all CUs (2 waves per SIMD), the shader cycles one
+ * SIMD spends per MFMA, and the clock (GHz) the chip held while running it.  Used to
+ * calibrate the roofline against what the silicon sustains rather than the datasheet. */
+int gpc_mfma_peak(gpc_ctx* ctx, int dtype, double* tflops, double* cycles_per_mfma,
+                  double* clock_ghz);
+
+/* ---- test hooks (exercise one kernel through the ABI; used by tests/ only) --------
+ * C[M x N] = beta*C + alpha*op(A)op(B) with the library's tiled MFMA GEMM.
+ * a_kmajor: A stored K x M (else M x K); b_kmajor: B stored K x N (else N x K).
+ * M, N, K multiples of 128.  klo/khi/lower_only: per-tile k-range modes (see
+ * gpyreg_amd/csrc/gemm.h).                                                         */
+int gpc_debug_gemm(gpc_ctx* ctx, int dtype, int M, int N, int K, int a_kmajor,
+                   int b_kmajor, double alpha, int beta, int klo, int khi,
+                   int lower_only, const double* A, const double* B, double* C);
+/* In-LDS leaf: A (128 x 128 SPD, lower used) -> L (lower) and W = L^-1; logdet, info */
+int gpc_debug_leaf(gpc_ctx* ctx, int dtype, const double* A, double* L, double* W,
+                   double* logdet, int* info);
+/* Blocked factorization of an n x n SPD matrix (any n): L, W = L^-1, Ainv (lower).   */
+int gpc_debug_factor(gpc_ctx* ctx, int dtype, int n, const double* A, double* L,
+                     double* W, double* Ainv, double* logdet, int* info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPCORE_H */

@@ -1,0 +1,138 @@
+"""NumPy model of the device algorithm (test helper, CPU only).
+
+The HIP library factors A = L L^T and forms W = L^-1 and A^-1 = W^T W using ONE
+tiled GEMM primitive with per-tile k-ranges plus a small in-LDS leaf.  This
+model executes exactly that launch plan (same primitive signature, same modes,
+same buffer roles A / W / T) with NumPy tiles, so that the plan itself --
+recursion order, triangular k-ranges, in-place hazards, identity padding -- is
+verified on the CPU.  `gpyreg_amd/csrc/gpcore_plan.h` implements the same plan.
+"""
+
+import numpy as np
+
+KLO_ZERO, KLO_ROW, KLO_COL = 0, 1, 2
+KHI_FULL, KHI_ROW, KHI_COL = 0, 1, 2
+
+
+def tiled_gemm(C, A, B, M, N, K, tile, *, a_kmajor, b_kmajor, alpha, beta,
+               klo=KLO_ZERO, khi=KHI_FULL, lower_only=False, log=None):
+    """C[M,N] = beta*C + alpha * Aop @ Bop computed tile by tile.
+
+    a_kmajor False: A is stored (M,K);  True: stored (K,M).
+    b_kmajor False: B is stored (N,K);  True: stored (K,N).
+    Each output tile (ti,tj) only sums k in [k0,k1) chosen by klo/khi.
+    Inputs are snapshotted per launch like a GPU would read them (the caller
+    must not alias C with A or B unless every tile only reads what it owns).
+    """
+    assert M % tile == 0 and N % tile == 0 and K % tile == 0
+    Ain, Bin = A.copy(), B.copy()  # catches accidental in-place aliasing below
+    aliased = np.shares_memory(C, A) or np.shares_memory(C, B)
+    assert not aliased, "plan must never alias output with an input"
+    for ti in range(M // tile):
+        for tj in range(N // tile):
+            if lower_only and tj > ti:
+                continue
+            k0 = {KLO_ZERO: 0, KLO_ROW: ti * tile, KLO_COL: tj * tile}[klo]
+            k1 = {KHI_FULL: K, KHI_ROW: (ti + 1) * tile, KHI_COL: (tj + 1) * tile}[khi]
+            k1 = min(k1, K)
+            r = slice(ti * tile, (ti + 1) * tile)
+            c = slice(tj * tile, (tj + 1) * tile)
+            acc = np.zeros((tile, tile))
+            if k1 > k0:
+                a = Ain[k0:k1, r].T if a_kmajor else Ain[r, k0:k1]
+                b = Bin[k0:k1, c] if b_kmajor else Bin[c, k0:k1].T
+                acc = a @ b
+            C[r, c] = (beta * C[r, c] if beta != 0 else 0) + alpha * acc
+            if log is not None:
+                log["flops"] = log.get("flops", 0) + 2 * tile * tile * max(k1 - k0, 0)
+
+
+def leaf(Ablk, Wblk):
+    """tile x tile Cholesky + inverse, in place (device: one workgroup in LDS).
+    Writes L into the lower triangle of Ablk (upper left untouched = garbage) and
+    the full tile of Wblk (zeros above the diagonal).  Returns info (0 = ok)."""
+    n = Ablk.shape[0]
+    L = np.tril(Ablk).copy()
+    for j in range(n):
+        d = L[j, j]
+        if not (d > 0):
+            return j + 1
+        d = np.sqrt(d)
+        L[j, j] = d
+        L[j + 1:, j] /= d
+        for k in range(j + 1, n):
+            L[k:, k] -= L[k:, j] * L[k, j]
+    Ablk[np.tril_indices(n)] = L[np.tril_indices(n)]
+    Wblk[:, :] = np.linalg.solve(L, np.eye(n))
+    Wblk[np.triu_indices(n, 1)] = 0.0
+    return 0
+
+
+def potrf_inv(A, W, T, off, n, tile, need_inv, post_mode, log=None):
+    """Recursive plan on the n x n diagonal block starting at `off`."""
+    if n == tile:
+        s = slice(off, off + n)
+        info = leaf(A[s, s], W[s, s])
+        if log is not None:
+            log["launches"] = log.get("launches", 0) + 1
+        return info + off if info else 0
+    q = n // tile
+    n1 = (q // 2) * tile if q > 1 else tile
+    n2 = n - n1
+    o1, o2 = off, off + n1
+    r1, r2 = slice(o1, o1 + n1), slice(o2, o2 + n2)
+    info = potrf_inv(A, W, T, o1, n1, tile, True, post_mode, log)
+    if info:
+        return info
+    # step 2: T21 = A21 * W11^T      (W11 lower: k <= col)
+    tiled_gemm(T[r2, r1], A[r2, r1], W[r1, r1], n2, n1, n1, tile, a_kmajor=False,
+               b_kmajor=False, alpha=1.0, beta=0.0, khi=KHI_COL, log=log)
+    # step 3: A22 -= T21 * T21^T     (lower tiles only)
+    tiled_gemm(A[r2, r2], T[r2, r1], T[r2, r1], n2, n2, n1, tile, a_kmajor=False,
+               b_kmajor=False, alpha=-1.0, beta=1.0, lower_only=True, log=log)
+    info = potrf_inv(A, W, T, o2, n2, tile, need_inv, post_mode, log)
+    if info:
+        return info
+    if need_inv:
+        # step 5a: U = T21 * W11      (W11 lower: k >= col); U lives in A21
+        tiled_gemm(A[r2, r1], T[r2, r1], W[r1, r1], n2, n1, n1, tile, a_kmajor=False,
+                   b_kmajor=True, alpha=1.0, beta=0.0, klo=KLO_COL, log=log)
+        # step 5b: W21 = -W22 * U     (W22 lower: k <= row)
+        tiled_gemm(W[r2, r1], W[r2, r2], A[r2, r1], n2, n1, n2, tile, a_kmajor=False,
+                   b_kmajor=True, alpha=-1.0, beta=0.0, khi=KHI_ROW, log=log)
+    if post_mode or not need_inv:
+        A[r2, r1] = T[r2, r1]  # keep L21 in A (posterior fetch / later solves)
+    if log is not None:
+        log["launches"] = log.get("launches", 0) + (4 if need_inv else 2)
+    return 0
+
+
+def lauum(Kinv, W, n, tile, log=None):
+    """Kinv = W^T W, lower tiles, k >= row tile."""
+    tiled_gemm(Kinv, W, W, n, n, n, tile, a_kmajor=True, b_kmajor=True, alpha=1.0,
+               beta=0.0, klo=KLO_ROW, lower_only=True, log=log)
+
+
+def pad_identity(Amat, tile):
+    n = Amat.shape[0]
+    npad = -(-n // tile) * tile
+    P = np.eye(npad)
+    P[:n, :n] = Amat
+    return P
+
+
+def forward_solve(A, W, r, off, n, tile, need_inv):
+    """z = L^-1 r using what potrf_inv(need_inv=...) left behind: a block that has
+    its full inverse multiplies by W (trmv); otherwise split like the factorization
+    and use L21 (kept in A for exactly these blocks)."""
+    if need_inv or n == tile:
+        s = slice(off, off + n)
+        r[s] = np.tril(W[s, s]) @ r[s]
+        return
+    q = n // tile
+    n1 = (q // 2) * tile if q > 1 else tile
+    n2 = n - n1
+    r1, r2 = slice(off, off + n1), slice(off + n1, off + n)
+    forward_solve(A, W, r, off, n1, tile, True)
+    r[r2] -= A[r2, r1] @ r[r1]
+    forward_solve(A, W, r, off + n1, n2, tile, need_inv)

@@ -1,0 +1,77 @@
+"""CPU check of the device launch plan (tests/blocked_model.py) against NumPy."""
+
+import numpy as np
+import pytest
+
+import blocked_model as bm
+
+
+def _spd(n, rng):
+    X = rng.uniform(-3, 3, (n, 2))
+    d = ((X[:, None, :] - X[None, :, :]) ** 2).sum(-1)
+    return np.exp(-0.5 * d) / 0.01 + np.eye(n)
+
+
+@pytest.mark.parametrize("n,tile", [(4, 4), (8, 4), (12, 4), (20, 4), (28, 4), (37, 4), (64, 8)])
+@pytest.mark.parametrize("post_mode", [False, True])
+def test_plan_factor_inverse(n, tile, post_mode):
+    rng = np.random.default_rng(n * 10 + tile)
+    A0 = _spd(n, rng)
+    A = bm.pad_identity(A0, tile)
+    npad = A.shape[0]
+    Aref = A.copy()
+    A[np.triu_indices(npad, 1)] = np.nan  # the plan must never read the upper part of A
+    W = np.zeros((npad, npad))
+    T = np.full((npad, npad), np.nan)
+    log = {}
+    info = bm.potrf_inv(A, W, T, 0, npad, tile, True, post_mode, log)
+    assert info == 0
+    Lref = np.linalg.cholesky(Aref)
+    Wref = np.linalg.inv(Lref)
+    assert np.allclose(np.diag(A), np.diag(Lref), rtol=1e-12)
+    if post_mode:
+        assert np.allclose(np.tril(A), Lref, rtol=1e-10, atol=1e-12)
+    assert np.allclose(W, Wref, rtol=1e-9, atol=1e-12)
+    assert np.all(W[np.triu_indices(npad, 1)] == 0)
+    Kinv = np.full((npad, npad), np.nan)
+    bm.lauum(Kinv, W, npad, tile, log)
+    ref = np.linalg.inv(Aref)
+    il = np.tril_indices(npad)
+    assert np.allclose(Kinv[il], ref[il], rtol=1e-8, atol=1e-12)
+    # identity padding stays exactly inert
+    if npad > n:
+        assert np.all(Kinv[n:, :n] == 0)
+        assert np.array_equal(np.tril(Kinv[n:, n:]), np.eye(npad - n))
+    # flop count approaches n^3 (potrf+trtri+lauum) for many tiles
+    if npad // tile >= 8:
+        assert log["flops"] < 1.6 * npad**3
+
+
+def test_plan_nll_only_mode_skips_top_level_inverse():
+    rng = np.random.default_rng(5)
+    n, tile = 32, 4
+    A0 = _spd(n, rng)
+    A = A0.copy()
+    W = np.zeros((n, n))
+    T = np.full((n, n), np.nan)
+    log = {}
+    assert bm.potrf_inv(A, W, T, 0, n, tile, False, False, log) == 0
+    Lref = np.linalg.cholesky(A0)
+    assert np.allclose(np.diag(A), np.diag(Lref), rtol=1e-12)
+    r = rng.standard_normal(n)
+    z = r.copy()
+    bm.forward_solve(A, W, z, 0, n, tile, False)
+    assert np.allclose(z, np.linalg.solve(Lref, r), rtol=1e-9, atol=1e-12)
+    full = {}
+    A2, W2, T2 = A0.copy(), np.zeros((n, n)), np.full((n, n), np.nan)
+    bm.potrf_inv(A2, W2, T2, 0, n, tile, True, False, full)
+    assert log["flops"] < 0.75 * full["flops"]
+
+
+def test_plan_reports_first_bad_pivot():
+    n, tile = 16, 4
+    A = np.eye(n)
+    A[9, 9] = -1.0
+    W = np.zeros((n, n))
+    T = np.zeros((n, n))
+    assert bm.potrf_inv(A, W, T, 0, n, tile, True, False) == 10
