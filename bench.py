@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- GP fit-evaluations/sec (NLL + gradient) on MI355X.
+
+A "step" is one batched pass of the hot path: `GP.nll_batch(hyp[S], compute_grad=True)`
+for S hyperparameter samples at the workload BASELINE.json's metric is quoted on
+(N=4096, D=10, Matern-5/2 ARD, ConstantMean, constant Gaussian noise, fp64).
+X and y are resident in HBM before the timed region; the per-step H2D of the
+hyperparameter-derived vectors and D2H of (nlZ, dnlZ) are inside it.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: one process per GPU; samples are independent units, sharded with no
+data-path collective ("weak": every rank evaluates its own S samples); the only
+exchange is the RCCL all-gather of the per-sample [nlZ | dnlZ] vectors, done every
+step.  Rank 0 prints ONE JSON line.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    2: dict(N=2048, D=5, kernel="se", degree=0, S=1),
+    3: dict(N=4096, D=10, kernel="matern", degree=5, S=16),
+    4: dict(N=16384, D=20, kernel="rq", degree=0, S=1),
+    5: dict(N=8192, D=8, kernel="se", degree=0, S=64),
+}
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X datasheet, dense fp64 matrix
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md chip table
+
+
+def synthetic_problem(cfg_idx, S, seed_shift=0):
+    """Seeded synthetic inputs of SURVEY.md 8(d): draw order X, y-noise, then hyp."""
+    c = CONFIGS[cfg_idx]
+    N, D = c["N"], c["D"]
+    rng = np.random.default_rng(1000 + cfg_idx)
+    X = rng.uniform(-3, 3, (N, D))
+    y = np.sin(np.sum(X, 1, keepdims=True) / np.sqrt(D)) + 0.1 * rng.standard_normal((N, 1))
+    base = [np.log(1.5 * np.sqrt(D) * (1 + 0.1 * d / D)) for d in range(D)] + [0.0]
+    if c["kernel"] == "rq":
+        base.append(0.0)
+    base += [np.log(0.1), 0.0]
+    base = np.asarray(base)
+    if seed_shift:
+        rng = np.random.default_rng(1000 + cfg_idx + 7919 * seed_shift)
+    hyp = base + 0.1 * rng.standard_normal((S, base.size))
+    return X, y, hyp
+
+
+def make_gp(cfg_idx, dtype):
+    import gpyreg_amd as gpr
+
+    c = CONFIGS[cfg_idx]
+    cov = {
+        "se": gpr.covariance_functions.SquaredExponential,
+        "rq": gpr.covariance_functions.RationalQuadraticARD,
+    }.get(c["kernel"])
+    cov = gpr.covariance_functions.Matern(c["degree"]) if c["kernel"] == "matern" else cov()
+    return gpr.GP(c["D"], cov, gpr.mean_functions.ConstantMean(),
+                  gpr.noise_functions.GaussianNoise(constant_add=True), dtype=dtype)
+
+
+def cpu_baseline(cfg_idx, X, y, hyp):
+    """The CPU oracle (NumPy/SciPy restatement pinned to the reference) timed on this
+    host: ONE NLL+gradient evaluation of the same workload (about 10-30 s)."""
+    from oracle import gp_oracle as orc  # cpu_baseline leg only
+
+    c = CONFIGS[cfg_idx]
+    model = dict(kernel=c["kernel"], degree=c["degree"], mean="const", noise=(1, 0, 0))
+    t0 = time.perf_counter()
+    nlz, _ = orc.core(model, hyp[0], X, y, None, 1, 1)
+    dt = time.perf_counter() - t0
+    return dict(value=1.0 / dt, unit="fit-evals/s", cores=os.cpu_count(), kind="port",
+                sample=f"1 of {hyp.shape[0]} hyperparameter samples, NLL+grad, N={c['N']} D={c['D']} "
+                       f"{c['kernel']}{c['degree'] or ''}, default BLAS threading, {dt:.2f} s",
+                nlz=float(nlz))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS))
+    ap.add_argument("--samples", type=int, default=0, help="hyperparameter samples per GPU (default: config's S)")
+    ap.add_argument("--dtype", default=None, choices=["f64", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--nll-only", action="store_true", help="time NLL without gradient")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    cfg = CONFIGS[args.config]
+    S = args.samples or cfg["S"]
+    dtype = args.dtype or ("f32" if args.config == 4 else "f64")
+
+    import torch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+
+    X, y, hyp = synthetic_problem(args.config, S, seed_shift=rank)
+    gp = make_gp(args.config, dtype)
+    gp.device = local_rank
+    gp.update(X_new=X, y_new=y, hyp=hyp[:1], compute_posterior=False)  # X, y -> HBM on first use
+    from gpyreg_amd import _lib
+
+    ctx = _lib.context(local_rank)
+    grad = not args.nll_only
+    hyp_N = hyp.shape[1]
+    gathered = None
+
+    def step():
+        nonlocal gathered
+        nlz, dnlz = gp.nll_batch(hyp, compute_grad=grad)
+        if world > 1:  # the one exchange step of the path: per-sample [nlZ | dnlZ]
+            loc = np.concatenate([nlz[:, None], dnlz if grad else np.zeros((S, 0))], axis=1)
+            t = torch.from_numpy(loc).to(dev)
+            out = torch.empty((world * t.shape[0], t.shape[1]), dtype=t.dtype, device=dev)
+            dist.all_gather_into_tensor(out, t)
+            gathered = out
+        return nlz, dnlz
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    fac_ms, tot_ms = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        nlz, dnlz = step()
+        a, b = ctx.last_timing()  # hipEvents on the library's own stream
+        tot_ms.append(a)
+        fac_ms.append(b)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        N = cfg["N"]
+        fits = S * args.steps * world
+        flops_per_launch = S * (float(N) ** 3 if grad else float(N) ** 3 / 3.0)
+        fac = float(np.mean(fac_ms)) * 1e-3
+        peak = FP64_MFMA_PEAK_TFLOPS if dtype == "f64" else FP32_MFMA_PEAK_TFLOPS
+        achieved = flops_per_launch / fac / 1e12
+        from gpyreg_amd import _lib as L_
+
+        tf, cyc, ghz = ctx.mfma_peak(L_.F64 if dtype == "f64" else L_.F32)
+        out = {
+            "metric": "GP-fits/sec (NLL+grad, N=4096 D=10)" if (args.config == 3 and grad)
+            else f"GP {'fits' if grad else 'NLL evals'}/sec (N={N} D={cfg['D']})",
+            "value": fits / dt,
+            "unit": "fit-evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": dtype,
+            "data": "synthetic",
+            "config": {
+                "workload": f"cfg{args.config}: N={N} D={cfg['D']} {cfg['kernel']}{cfg['degree'] or ''} ARD, "
+                            f"ConstantMean, GaussianNoise(constant), NLL{'+grad' if grad else ''}",
+                "samples_per_gpu": S,
+                "global_samples": S * world,
+                "sharding": f"hyperparameter samples x{world}",
+            },
+            "roofline": {
+                "bound": "mfma",
+                "kernel": "blocked potrf + trtri + lauum (gemm_kernel + leaf_kernel launches of one batch)",
+                "achieved": achieved,
+                "peak": peak,
+                "unit": "TFLOP/s",
+                "frac": achieved / peak,
+                "traffic": None,
+                "flops_per_launch": flops_per_launch,
+                "launch_ms": fac * 1e3,
+                "device_ms_per_step": float(np.mean(tot_ms)),
+                "measured_mfma_ceiling": {"tflops": tf, "cycles_per_mfma_per_simd": cyc, "clock_ghz": ghz},
+            },
+            "nlz_sample0": float(nlz[0]),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.config, X, y, hyp)
+            out["vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -170,26 +170,26 @@ __global__ void rect_copy_kernel(const T* __restrict__ src, long long sS, int ld
 }
 
 // register-resident MFMA issue loop: the measured ceiling the roofline is quoted against
-template <typename T>
+template <typename T, int NACC>
 __global__ __launch_bounds__(256) void mfma_peak_kernel(T* out, int iters, long long* clk) {
   using acc_t = typename MM<T>::acc_t;
-  acc_t acc[8];
+  acc_t acc[NACC];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = acc_t{0, 0, 0, 0};
+  for (int i = 0; i < NACC; ++i) acc[i] = acc_t{0, 0, 0, 0};
   T a = (T)(threadIdx.x * 1e-3), bq = (T)(1.0 + threadIdx.x * 1e-4);
   const long long c0 = clock64(), w0 = wall_clock64();
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = MM<T>::mma(a, bq, acc[i]);
+    for (int i = 0; i < NACC; ++i) acc[i] = MM<T>::mma(a, bq, acc[i]);
   }
   const long long c1 = clock64(), w1 = wall_clock64();
   if (clk && blockIdx.x == 0 && threadIdx.x == 0) {
-    clk[0] = c1 - c0;  // shader cycles for iters*8 MFMAs of this wave
+    clk[0] = c1 - c0;  // shader-clock ticks for iters*NACC MFMAs of this wave
     clk[1] = w1 - w0;  // 100 MHz reference ticks
   }
   T s = 0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
   out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
 }
 

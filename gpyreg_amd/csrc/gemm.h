@@ -44,7 +44,7 @@ struct GemmArgs {
   double alpha;
   int beta;  // 0 or 1
   int klo, khi, lower_only;
-  int tiles_n;
+  int tiles_m, tiles_n;
 };
 
 template <typename T, bool KM>
@@ -129,12 +129,26 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   const int t = threadIdx.x;
   const int lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
 
+  // Tile order = dispatch order.  Tiles differ in k-length when the k-range is
+  // triangular, so the longest tiles go first (LPT) and the short ones fill the tail;
+  // the major index is the one the k-range depends on, which also keeps consecutive
+  // blocks on one operand panel.
   int ti, tj;
+  const int bx = blockIdx.x;
   if (g.lower_only) {
-    tri_tile(blockIdx.x, ti, tj);
+    tri_tile(bx, ti, tj);  // ti ascending: longest first for KLO_ROW (lauum), uniform for syrk
+  } else if (g.khi == KHI_COL) {
+    tj = g.tiles_n - 1 - bx / g.tiles_m;
+    ti = bx % g.tiles_m;
+  } else if (g.klo == KLO_COL) {
+    tj = bx / g.tiles_m;
+    ti = bx % g.tiles_m;
+  } else if (g.khi == KHI_ROW) {
+    ti = g.tiles_m - 1 - bx / g.tiles_n;
+    tj = bx % g.tiles_n;
   } else {
-    ti = blockIdx.x / g.tiles_n;
-    tj = blockIdx.x % g.tiles_n;
+    ti = bx / g.tiles_n;
+    tj = bx % g.tiles_n;
   }
   const int m0 = ti * TILE, n0 = tj * TILE;
   int k0 = g.klo == KLO_ROW ? m0 : (g.klo == KLO_COL ? n0 : 0);
@@ -208,6 +222,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 template <typename T>
 inline hipError_t launch_gemm(hipStream_t st, GemmArgs g, bool akm, bool bkm, int batch) {
   const int tm = g.M / TILE, tn = g.N / TILE;
+  g.tiles_m = tm;
   g.tiles_n = tn;
   const int ntiles = g.lower_only ? tm * (tm + 1) / 2 : tm * tn;
   if (ntiles <= 0 || batch <= 0) return hipSuccess;

@@ -1028,32 +1028,50 @@ int gpc_mfma_peak(gpc_ctx* c, int dtype, double* tflops, double* cycles_per_mfma
   HIPCHK(c, hipSetDevice(c->device));
   hipDeviceProp_t prop;
   HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
-  const int blocks = prop.multiProcessorCount * 2;  // 8 waves per CU = 2 per SIMD
-  const int iters = 4096;
-  HIPCHK(c, c->dbg1.ensure((size_t)blocks * 256 * 8));
+  const int iters = 2048;
+  HIPCHK(c, c->dbg1.ensure((size_t)prop.multiProcessorCount * 2 * 256 * 8));
   HIPCHK(c, c->dbg2.ensure(64));
   long long* d_clk = c->dbg2.as<long long>();
-  auto launch = [&]() {
-    if (dtype == GPC_F64)
-      hipLaunchKernelGGL((mfma_peak_kernel<double>), dim3(blocks), dim3(256), 0, c->st, c->dbg1.as<double>(), iters, d_clk);
-    else
-      hipLaunchKernelGGL((mfma_peak_kernel<float>), dim3(blocks), dim3(256), 0, c->st, c->dbg1.as<float>(), iters, d_clk);
-  };
-  launch();
-  HIPCHK(c, hipStreamSynchronize(c->st));
-  HIPCHK(c, hipEventRecord(c->ev[0], c->st));
-  const int reps = 5;
-  for (int r = 0; r < reps; ++r) launch();
-  HIPCHK(c, hipEventRecord(c->ev[1], c->st));
-  HIPCHK(c, hipStreamSynchronize(c->st));
-  float ms = 0;
-  HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
-  const double flops = (double)reps * blocks * 4.0 /*waves*/ * iters * 8.0 * (2.0 * 16 * 16 * 4);
-  *tflops = flops / (ms * 1e-3) / 1e12;
-  long long hclk[2] = {0, 0};
-  HIPCHK(c, hipMemcpy(hclk, d_clk, sizeof hclk, hipMemcpyDeviceToHost));
-  if (cycles_per_mfma) *cycles_per_mfma = (double)hclk[0] / ((double)iters * 8.0) / 2.0;  // 2 waves share a SIMD
-  if (clock_ghz) *clock_ghz = hclk[1] > 0 ? (double)hclk[0] / ((double)hclk[1] * 10.0) / 1.0 : 0.0;  // cycles per ns
+  double best = 0, best_cyc = 0, best_ghz = 0;
+  // variants: accumulators per wave x waves per SIMD; the best one is the ceiling
+  for (int nacc : {4, 16})
+    for (int wps : {1, 2}) {
+      const int blocks = prop.multiProcessorCount * wps;
+      auto launch = [&]() {
+        if (dtype == GPC_F64) {
+          if (nacc == 4)
+            hipLaunchKernelGGL((mfma_peak_kernel<double, 4>), dim3(blocks), dim3(256), 0, c->st, c->dbg1.as<double>(), iters, d_clk);
+          else
+            hipLaunchKernelGGL((mfma_peak_kernel<double, 16>), dim3(blocks), dim3(256), 0, c->st, c->dbg1.as<double>(), iters, d_clk);
+        } else {
+          if (nacc == 4)
+            hipLaunchKernelGGL((mfma_peak_kernel<float, 4>), dim3(blocks), dim3(256), 0, c->st, c->dbg1.as<float>(), iters, d_clk);
+          else
+            hipLaunchKernelGGL((mfma_peak_kernel<float, 16>), dim3(blocks), dim3(256), 0, c->st, c->dbg1.as<float>(), iters, d_clk);
+        }
+      };
+      launch();
+      HIPCHK(c, hipStreamSynchronize(c->st));
+      HIPCHK(c, hipEventRecord(c->ev[0], c->st));
+      const int reps = 4;
+      for (int r = 0; r < reps; ++r) launch();
+      HIPCHK(c, hipEventRecord(c->ev[1], c->st));
+      HIPCHK(c, hipStreamSynchronize(c->st));
+      float ms = 0;
+      HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+      const double flops = (double)reps * blocks * 4.0 * iters * nacc * (2.0 * 16 * 16 * 4);
+      const double tf = flops / (ms * 1e-3) / 1e12;
+      long long hclk[2] = {0, 0};
+      HIPCHK(c, hipMemcpy(hclk, d_clk, sizeof hclk, hipMemcpyDeviceToHost));
+      if (tf > best) {
+        best = tf;
+        best_cyc = (double)hclk[0] / ((double)iters * nacc) / wps;  // per MFMA per SIMD
+        best_ghz = hclk[1] > 0 ? (double)hclk[0] / ((double)hclk[1] * 10.0) : 0.0;
+      }
+    }
+  *tflops = best;
+  if (cycles_per_mfma) *cycles_per_mfma = best_cyc;
+  if (clock_ghz) *clock_ghz = best_ghz;
   return 0;
 }
 

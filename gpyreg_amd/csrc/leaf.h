@@ -22,10 +22,24 @@
 
 namespace gpc {
 
+// 1/sqrt(x) to working precision from the hardware estimate plus Newton steps (the
+// pivot's square root and reciprocal sit on the serial critical path of every step)
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = r * (1.5 - 0.5 * x * r * r);
+  r = r * (1.5 - 0.5 * x * r * r);
+  return r;
+}
+__device__ __forceinline__ float fast_rsqrt(float x) {
+  float r = __builtin_amdgcn_rsqf(x);
+  r = r * (1.5f - 0.5f * x * r * r);
+  return r;
+}
+
 template <typename T, int JB>
 __device__ __forceinline__ void leaf_steps(T (&M)[8][8], T* __restrict__ colbuf,
-                                           T* __restrict__ rowbuf, T* __restrict__ Aout, int lda,
-                                           int tx, int ty, double& logacc, int& bad) {
+                                           T* __restrict__ rowbuf, T* __restrict__ dbuf,
+                                           T* __restrict__ Aout, int lda, int tx, int ty, int& bad) {
   for (int jj = 0; jj < 16; ++jj) {
     const int j = JB * 16 + jj;
     T* cb = colbuf + (j & 1) * TILE;
@@ -41,9 +55,9 @@ __device__ __forceinline__ void leaf_steps(T (&M)[8][8], T* __restrict__ colbuf,
     __syncthreads();
     const T piv = cb[j];
     if (!(piv > (T)0) && bad == 0) bad = j + 1;
-    const T d = sqrt(piv);
-    const T rinv = (T)1 / d;
-    logacc += log((double)d);
+    const T rinv = fast_rsqrt(piv);
+    const T d = piv * rinv;
+    if (tx == jj && ty == jj) dbuf[j] = d;
 
     T c[8], v[8];
 #pragma unroll
@@ -77,7 +91,12 @@ __device__ __forceinline__ void leaf_steps(T (&M)[8][8], T* __restrict__ colbuf,
       const bool active = (a > JB) || (ty > jj);
       if (active) {
 #pragma unroll
-        for (int b = 0; b < 8; ++b) M[a][b] -= c[a] * v[b];
+        for (int b = 0; b < 8; ++b) {
+          // columns right of the pivot block still hold A: only its lower triangle is
+          // ever read, so blocks strictly above the diagonal are skipped
+          if (b > JB && b > a) continue;
+          M[a][b] -= c[a] * v[b];
+        }
       }
     }
     // pivot row becomes the final row j of W (zeros right of the diagonal)
@@ -99,6 +118,8 @@ __global__ __launch_bounds__(256) void leaf_kernel(T* __restrict__ A, long long 
                                                    int* __restrict__ info) {
   __shared__ T colbuf[2 * TILE];
   __shared__ T rowbuf[2 * TILE];
+  __shared__ T dbuf[TILE];
+  __shared__ double red4[4];
   const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
   T* Ab = A + (size_t)blockIdx.x * sA;
   T* Wb = W + (size_t)blockIdx.x * sW;
@@ -112,16 +133,15 @@ __global__ __launch_bounds__(256) void leaf_kernel(T* __restrict__ A, long long 
       M[a][b] = (k <= i) ? Ab[(size_t)i * lda + k] : (T)0;
     }
 
-  double logacc = 0.0;
   int bad = 0;
-  leaf_steps<T, 0>(M, colbuf, rowbuf, Ab, lda, tx, ty, logacc, bad);
-  leaf_steps<T, 1>(M, colbuf, rowbuf, Ab, lda, tx, ty, logacc, bad);
-  leaf_steps<T, 2>(M, colbuf, rowbuf, Ab, lda, tx, ty, logacc, bad);
-  leaf_steps<T, 3>(M, colbuf, rowbuf, Ab, lda, tx, ty, logacc, bad);
-  leaf_steps<T, 4>(M, colbuf, rowbuf, Ab, lda, tx, ty, logacc, bad);
-  leaf_steps<T, 5>(M, colbuf, rowbuf, Ab, lda, tx, ty, logacc, bad);
-  leaf_steps<T, 6>(M, colbuf, rowbuf, Ab, lda, tx, ty, logacc, bad);
-  leaf_steps<T, 7>(M, colbuf, rowbuf, Ab, lda, tx, ty, logacc, bad);
+  leaf_steps<T, 0>(M, colbuf, rowbuf, dbuf, Ab, lda, tx, ty, bad);
+  leaf_steps<T, 1>(M, colbuf, rowbuf, dbuf, Ab, lda, tx, ty, bad);
+  leaf_steps<T, 2>(M, colbuf, rowbuf, dbuf, Ab, lda, tx, ty, bad);
+  leaf_steps<T, 3>(M, colbuf, rowbuf, dbuf, Ab, lda, tx, ty, bad);
+  leaf_steps<T, 4>(M, colbuf, rowbuf, dbuf, Ab, lda, tx, ty, bad);
+  leaf_steps<T, 5>(M, colbuf, rowbuf, dbuf, Ab, lda, tx, ty, bad);
+  leaf_steps<T, 6>(M, colbuf, rowbuf, dbuf, Ab, lda, tx, ty, bad);
+  leaf_steps<T, 7>(M, colbuf, rowbuf, dbuf, Ab, lda, tx, ty, bad);
 
 #pragma unroll
   for (int a = 0; a < 8; ++a)
@@ -130,9 +150,11 @@ __global__ __launch_bounds__(256) void leaf_kernel(T* __restrict__ A, long long 
       const int i = ty + 16 * a, k = tx + 16 * b;
       Wb[(size_t)i * ldw + k] = M[a][b];
     }
+  __syncthreads();
+  const double lg = block_sum_256(t < TILE ? log((double)dbuf[t]) : 0.0, red4);
   if (t == 0) {
     if (bad) atomicCAS(info + blockIdx.x, 0, off + bad);
-    atomicAdd(logdet + blockIdx.x, logacc);
+    atomicAdd(logdet + blockIdx.x, lg);
   }
 }
 

@@ -1,0 +1,483 @@
+"""GP -- the reference's user-facing class for the dense hot path, MI355X-native.
+
+Mirrors ``gpyreg.GP`` (reference gaussian_process.py:24) for everything on the path
+this package accelerates: construction from the three plugin objects, ``update``
+(full-recompute loop :870-884), ``predict`` (:1663-1816), ``log_likelihood`` /
+``log_posterior`` (:1468-1518), the name-mangled ``_GP__compute_nlZ`` (:1520) the
+reference's tests call, hyperparameter get/set and dict conversion (:516-689),
+``clean`` (:886-905) and the ``Posterior`` record (:2568-2586).
+
+All O(N^2) / O(N^3) arithmetic runs in libgpcore.so (HIP, gfx950): hyperparameter
+vectors are evaluated in BATCHES (``nll_batch``) -- one launch sequence covers all
+samples -- and posteriors stay resident in HBM; ``Posterior.alpha/.sW/.L`` are
+materialised as NumPy arrays lazily on first access.  There is no NumPy/SciPy
+fallback for the core: without the HIP library or a GPU these methods raise.
+"""
+
+from __future__ import annotations
+
+from textwrap import indent
+from typing import Union
+
+import numpy as np
+from numpy.linalg import LinAlgError  # scipy.linalg.LinAlgError is this class
+
+from . import _lib
+from .covariance_functions import AbstractKernel
+
+
+class Posterior:
+    """The reference's posterior record (gaussian_process.py:2568-2586).
+
+    ``alpha``  = (K + sn2_mult*Sigma)^-1 (y - m)            shape (N, 1)
+    ``sW``     = 1/sqrt(min(sn2) * sn2_mult)                 shape (N, 1)
+    ``L``      = upper Cholesky factor of (K + mult*Sigma)/sl when ``L_chol`` (a
+                 Fortran-ordered array like SciPy's), else -(K + mult*Sigma)^-1
+    Fields backed by device memory are fetched on first access and then cached;
+    assigning to them (as ``GP.clean`` does) detaches them from the device copy.
+    """
+
+    def __init__(self, hyp, alpha, sW, L, sn2_mult, Lchol, _handle=None, _index=None):
+        self.hyp = hyp
+        self._alpha, self._sW, self._L = alpha, sW, L
+        self.sn2_mult = sn2_mult
+        self.L_chol = Lchol
+        self._handle, self._index = _handle, _index
+        self._have = {"alpha": alpha is not None, "sW": sW is not None, "L": L is not None}
+
+    def _fetch(self, what):
+        if self._have[what] or self._handle is None:
+            return
+        a, w, Lm = self._handle.fetch(
+            self._index, alpha=(what == "alpha"), sW=(what == "sW"), L=(what == "L")
+        )
+        if what == "alpha":
+            self._alpha = a.reshape(-1, 1)
+        elif what == "sW":
+            self._sW = w.reshape(-1, 1)
+        else:
+            self._L = Lm.T if self.L_chol else Lm  # lower factor^T = SciPy's upper U
+        self._have[what] = True
+
+    @property
+    def alpha(self):
+        self._fetch("alpha")
+        return self._alpha
+
+    @alpha.setter
+    def alpha(self, v):
+        self._alpha, self._have["alpha"] = v, True
+
+    @property
+    def sW(self):
+        self._fetch("sW")
+        return self._sW
+
+    @sW.setter
+    def sW(self, v):
+        self._sW, self._have["sW"] = v, True
+
+    @property
+    def L(self):
+        self._fetch("L")
+        return self._L
+
+    @L.setter
+    def L(self, v):
+        self._L, self._have["L"] = v, True
+
+    def _detach(self):
+        self._handle = None
+
+
+_DTYPES = {"f64": _lib.F64, "fp64": _lib.F64, "float64": _lib.F64,
+           "f32": _lib.F32, "fp32": _lib.F32, "float32": _lib.F32}
+
+
+class GP:
+    """A single Gaussian process (reference gaussian_process.py:24-62).
+
+    Parameters are the reference's (``D``, ``covariance``, ``mean``, ``noise``) plus
+    two build-only keywords: ``device`` (HIP device index, default LOCAL_RANK or 0)
+    and ``dtype`` ("f64" default, or "f32" for the factorization arithmetic).
+    """
+
+    def __init__(self, D: int, covariance: object, mean: object, noise: object,
+                 device: int | None = None, dtype: str = "f64"):
+        self.D = D
+        self.covariance = covariance
+        self.mean = mean
+        self.noise = noise
+        self.s2 = None
+        self.X = None
+        self.y = None
+        self.posteriors = None
+        self.no_prior = True
+        self.temporary_data = {}
+        self.device = device
+        if dtype not in _DTYPES:
+            raise ValueError("dtype must be 'f64' or 'f32'")
+        self.dtype = dtype
+        self._token = None
+        self._post_handle = None
+        if getattr(covariance, "_gpc_kernel_id", None) is None:
+            raise NotImplementedError(
+                "gpyreg_amd.GP runs the covariance on the device and supports the built-in "
+                "kernels (SquaredExponential, Matern, RationalQuadraticARD and the isotropic "
+                "variants); user-defined Python kernels are not on the accelerated path."
+            )
+
+    # ------------------------------------------------------------------ plumbing
+    def _counts(self):
+        cov_N = self.covariance.hyperparameter_count(self.D)
+        mean_N = self.mean.hyperparameter_count(self.D)
+        noise_N = self.noise.hyperparameter_count()
+        return cov_N, noise_N, mean_N
+
+    def _ctx(self):
+        ctx = _lib.context(self.device)
+        if self.X is None or self.y is None:
+            raise ValueError("GP has no training data")
+        if ctx.data_token is not self._token or self._token is None:
+            self._token = object()
+            ctx.set_data(self.X, self.y, self._token)
+        return ctx
+
+    def _plugin_values(self, hyp: np.ndarray, grad: bool):
+        """Evaluate the O(N*D) boundary plugins for every sample
+        (gaussian_process.py:2371-2400): m (S,N), sn2 (S,N|1), dm, dsn2."""
+        cov_N, noise_N, mean_N = self._counts()
+        S = hyp.shape[0]
+        N = self.X.shape[0]
+        m = np.empty((S, N))
+        sn2_rows, dm_rows, dsn2_rows = [], [], []
+        vec = False
+        for s in range(S):
+            h_noise = hyp[s, cov_N:cov_N + noise_N]
+            h_mean = hyp[s, cov_N + noise_N:cov_N + noise_N + mean_N]
+            if grad:
+                sn2, dsn2 = self.noise.compute(h_noise, self.X, self.y, self.s2, compute_grad=True)
+                ms, dm = self.mean.compute(h_mean, self.X, compute_grad=True)
+                if mean_N > 0:
+                    dm_rows.append(np.asarray(dm, dtype=float).reshape(N, mean_N))
+                if noise_N > 0:
+                    dsn2_rows.append(np.asarray(dsn2, dtype=float))
+            else:
+                sn2 = self.noise.compute(h_noise, self.X, self.y, self.s2)
+                ms = self.mean.compute(h_mean, self.X)
+            m[s] = np.reshape(ms, (-1,))
+            vec = not np.isscalar(sn2)
+            sn2_rows.append(np.ravel(sn2) if vec else np.array([float(sn2)]))
+        out = {"m": m, "sn2": np.stack(sn2_rows), "vec": vec}
+        out["dm"] = np.stack(dm_rows) if (grad and mean_N > 0) else None
+        out["dsn2"] = np.stack(dsn2_rows) if (grad and noise_N > 0) else None
+        return out
+
+    def _kid(self):
+        return self.covariance._gpc_kernel_id, self.covariance._gpc_degree
+
+    # ------------------------------------------------------------------ core (batched)
+    def nll_batch(self, hyp: np.ndarray, compute_grad: bool = False):
+        """Negative log marginal likelihood (and gradient) for MANY hyperparameter
+        vectors at once: ``hyp`` (S, hyp_N) -> nlZ (S,), dnlZ (S, hyp_N) | None.
+
+        Equivalent to S calls of the reference's ``__core_computation(hyp, 1, grad)``
+        (gaussian_process.py:2357-2512); raises ``LinAlgError`` if any sample is
+        still not positive definite after the 10 jitter escalations.
+        """
+        hyp = np.atleast_2d(np.asarray(hyp, dtype=float))
+        cov_N, noise_N, mean_N = self._counts()
+        if hyp.shape[1] != cov_N + noise_N + mean_N:
+            raise ValueError("Input hyperparameter array is the wrong shape!")
+        ctx = self._ctx()
+        pv = self._plugin_values(hyp, compute_grad)
+        kid, deg = self._kid()
+        nlz, dnlz, mult, lchol, info = ctx.nll_batch(
+            kid, deg, _DTYPES[self.dtype], hyp[:, :cov_N], pv["m"], pv["sn2"], pv["vec"],
+            compute_grad, pv["dm"], pv["dsn2"])
+        if np.any(info != 0):
+            raise LinAlgError("Singular matrix for L Cholesky decomposition")
+        return nlz, dnlz
+
+    def __compute_nlZ(self, hyp, compute_grad, compute_prior):
+        """Reference gaussian_process.py:1520-1538 (single hyperparameter vector)."""
+        hyp = np.asarray(hyp, dtype=float)
+        nlz, dnlz = self.nll_batch(hyp[None, :], compute_grad)
+        nlZ = float(nlz[0])
+        if compute_prior and self.no_prior is not True:
+            raise NotImplementedError("hyperparameter priors are outside the accelerated path")
+        if compute_grad:
+            return nlZ, dnlz[0]
+        return nlZ
+
+    def log_likelihood(self, hyp: object, compute_grad: bool = False):
+        """(Positive) log marginal likelihood (reference :1468-1488).  With
+        ``compute_grad`` the reference negates a tuple (a TypeError); here the pair
+        (lZ, dlZ) is returned."""
+        if isinstance(hyp, dict):
+            hyp = self.hyperparameters_from_dict(hyp)[0]
+        r = self.__compute_nlZ(np.asarray(hyp, dtype=float).ravel(), compute_grad, False)
+        if compute_grad:
+            return -r[0], -r[1]
+        return -r
+
+    def log_posterior(self, hyp: object, compute_grad: bool = False):
+        """Log marginal likelihood plus log prior (reference :1490-1518)."""
+        if isinstance(hyp, dict):
+            hyp = self.hyperparameters_from_dict(hyp)[0]
+        r = self.__compute_nlZ(np.asarray(hyp, dtype=float).ravel(), compute_grad, True)
+        if compute_grad:
+            return -r[0], -r[1]
+        return -r
+
+    # ------------------------------------------------------------------ hyperparameters
+    def get_hyperparameters(self, as_array: bool = False):
+        """Reference :516-552."""
+        if self.posteriors is None:
+            cov_N, noise_N, mean_N = self._counts()
+            hyp = np.full((1, cov_N + mean_N + noise_N), np.nan)
+        else:
+            hyp = np.zeros((np.size(self.posteriors), np.size(self.posteriors[0].hyp)))
+            for i in range(np.size(self.posteriors)):
+                hyp[i, :] = self.posteriors[i].hyp.copy()
+        if as_array:
+            return hyp
+        return self.hyperparameters_to_dict(hyp)
+
+    def set_hyperparameters(self, hyp_new: object, compute_posterior: bool = True):
+        """Reference :554-593."""
+        if isinstance(hyp_new, np.ndarray):
+            cov_N, noise_N, mean_N = self._counts()
+            if hyp_new.ndim == 1:
+                hyp_new = np.reshape(hyp_new, (1, -1))
+            if hyp_new.shape[1] != cov_N + mean_N + noise_N:
+                raise ValueError("Input hyperparameter array is the wrong shape!")
+            self.update(hyp=hyp_new, compute_posterior=compute_posterior)
+        else:
+            self.update(hyp=self.hyperparameters_from_dict(hyp_new),
+                        compute_posterior=compute_posterior)
+
+    def _hyper_info(self):
+        return (self.covariance.hyperparameter_info(self.D)
+                + self.noise.hyperparameter_info()
+                + self.mean.hyperparameter_info(self.D))
+
+    def hyperparameters_to_dict(self, hyp_arr: np.ndarray):
+        """Reference :595-647: order is [covariance | noise | mean]."""
+        cov_N, noise_N, mean_N = self._counts()
+        if hyp_arr.ndim == 1:
+            hyp_arr = np.reshape(hyp_arr, (1, -1))
+        if hyp_arr.shape[1] != cov_N + mean_N + noise_N:
+            raise ValueError("Input hyperparameter array is the wrong shape!")
+        out = []
+        for r in range(hyp_arr.shape[0]):
+            row = hyp_arr[r, :].copy()
+            d, i = {}, 0
+            for name, cnt in self._hyper_info():
+                d[name] = row[i:i + cnt]
+                i += cnt
+            out.append(d)
+        return out
+
+    def hyperparameters_from_dict(self, hyp_dict_list):
+        """Reference :649-689."""
+        if isinstance(hyp_dict_list, dict):
+            hyp_dict_list = [hyp_dict_list]
+        cov_N, noise_N, mean_N = self._counts()
+        arr = np.zeros((len(hyp_dict_list), cov_N + mean_N + noise_N))
+        for r, d in enumerate(hyp_dict_list):
+            j = 0
+            for name, cnt in self._hyper_info():
+                arr[r, j:j + cnt] = d[name]
+                j += cnt
+        return arr
+
+    # ------------------------------------------------------------------ data / posterior
+    def update(self, X_new=None, y_new=None, s2_new=None, hyp=None, compute_posterior: bool = True):
+        """Add data and/or replace hyperparameters, then rebuild every posterior
+        (reference :691-884).  The reference's rank-one shortcut for a single new
+        point (:750-844) is replaced by the same full recompute it falls back to:
+        on the device an N^3/3 refactorization is cheaper than shipping L back."""
+        X_new, y_new, s2_new = self._convert_shapes(X_new, y_new, s2_new)
+        if X_new is not None:
+            X_new = X_new.copy()
+        if y_new is not None:
+            y_new = y_new.copy()
+        if s2_new is not None:
+            s2_new = s2_new.copy()
+        if hyp is not None:
+            hyp = np.atleast_2d(np.asarray(hyp, dtype=float)).copy()
+
+        if X_new is not None:
+            self.X = X_new if self.X is None else np.concatenate((self.X, X_new))
+        if y_new is not None:
+            self.y = y_new if self.y is None else np.concatenate((self.y, y_new))
+        if s2_new is not None:
+            self.s2 = s2_new if self.s2 is None else np.concatenate((self.s2, s2_new))
+        if X_new is not None or y_new is not None:
+            self._token = None  # device copy of X, y is stale
+
+        if hyp is None:
+            hyp = self.get_hyperparameters(as_array=True)
+        s_N = hyp.shape[0]
+        self._drop_handle()
+        self.posteriors = np.empty((s_N,), dtype=Posterior)
+        if compute_posterior and self.X is not None and self.y is not None:
+            self._compute_posteriors(hyp)
+        else:
+            for i in range(s_N):
+                self.posteriors[i] = Posterior(hyp[i, :], None, None, None, None, None)
+
+    def _compute_posteriors(self, hyp):
+        """S x ``__core_computation(hyp, 0, 0)`` (reference :876-879) in one batch."""
+        cov_N, _, _ = self._counts()
+        ctx = self._ctx()
+        pv = self._plugin_values(hyp, False)
+        kid, deg = self._kid()
+        handle, mult, lchol, info = ctx.posterior_batch(
+            kid, deg, _DTYPES[self.dtype], hyp[:, :cov_N], pv["m"], pv["sn2"], pv["vec"])
+        if np.any(info != 0):
+            handle.free()
+            raise LinAlgError("Singular matrix for L Cholesky decomposition")
+        self._post_handle = handle
+        for i in range(hyp.shape[0]):
+            m = mult[i]
+            self.posteriors[i] = Posterior(
+                hyp[i, :], None, None, None, int(m) if m < 2**62 else m, bool(lchol[i]),
+                _handle=handle, _index=i)
+
+    def _drop_handle(self):
+        if self._post_handle is not None:
+            if self.posteriors is not None:
+                for p in self.posteriors:
+                    if p is not None:
+                        p._detach()
+            self._post_handle.free()
+            self._post_handle = None
+
+    def clean(self):
+        """Drop the auxiliary structures (reference :886-905); ``update`` rebuilds them."""
+        self.temporary_data = {}
+        if self.posteriors is not None:
+            for p in self.posteriors:
+                p.alpha = None
+                p.sW = None
+                p.L = None
+                p.sn2_mult = None
+                p.L_chol = None
+        self._drop_handle()
+
+    # ------------------------------------------------------------------ predict
+    def predict(self, x_star, y_star=None, s2_star=None, add_noise: bool = False,
+                separate_samples: bool = False, return_lpd: bool = False):
+        """Posterior mean and variance at ``x_star`` (reference :1663-1816).  The K*
+        products and solves for all hyperparameter samples run in one device batch."""
+        x_star, y_star, s2_star = self._convert_shapes(x_star, y_star, s2_star)
+        s_N = self.posteriors.size
+        N_star, D = x_star.shape
+        cov_N, noise_N, mean_N = self._counts()
+        if return_lpd and y_star is None:
+            raise ValueError("Cannot calculate log predictive density without y_star.")
+
+        mu = np.zeros((N_star, s_N))
+        s2 = np.zeros((N_star, s_N))
+        if self.y is not None:
+            if self._post_handle is None:
+                raise ValueError("posteriors have been cleaned; call update() first")
+            self._ctx()
+            fmu, fs2 = self._post_handle.predict(x_star)
+        y_s2 = np.zeros((N_star, s_N)) if (return_lpd or add_noise) else None
+        lpd = np.zeros((N_star, s_N)) if (return_lpd and separate_samples) else None
+
+        for s in range(s_N):
+            hyp = self.posteriors[s].hyp
+            m_star = np.reshape(
+                self.mean.compute(hyp[cov_N + noise_N:cov_N + noise_N + mean_N], x_star), (-1,))
+            if self.y is not None:
+                mu[:, s] = m_star + fmu[:, s]
+                s2[:, s] = fs2[:, s]
+            else:
+                mu[:, s] = m_star
+                s2[:, s] = self.covariance.compute(hyp[0:cov_N], x_star, compute_diag=True)[:, 0]
+            s2[:, s] = np.maximum(s2[:, s], 0)  # :1770
+            if return_lpd or add_noise:
+                sn2_mult = self.posteriors[s].sn2_mult
+                if sn2_mult is None:
+                    sn2_mult = 1
+                sn2_star = self.noise.compute(hyp[cov_N:cov_N + noise_N], x_star, y_star, s2_star)
+                y_s2[:, s:s + 1] = s2[:, s:s + 1] + sn2_star * sn2_mult
+            if return_lpd and separate_samples:
+                lpd[:, s:s + 1] = -0.5 * (y_star - mu[:, s:s + 1]) ** 2 / y_s2[:, s:s + 1] \
+                    - 0.5 * np.log(2 * np.pi * y_s2[:, s:s + 1])
+
+        if add_noise:
+            s2 = y_s2
+        if not separate_samples:
+            if s_N > 1:
+                mu_bar = np.reshape(np.sum(mu, 1), (-1, 1)) / s_N
+                v = np.sum((mu - mu_bar) ** 2, 1) / (s_N - 1)
+                s2 = np.reshape(np.sum(s2, 1) / s_N + v, (-1, 1))
+                mu = mu_bar
+            else:
+                v = 0
+            if return_lpd and add_noise:
+                lpd = -0.5 * (y_star - mu) ** 2 / s2 - 0.5 * np.log(2 * np.pi * s2)
+            elif return_lpd:
+                y_s2 = np.reshape(np.sum(y_s2, 1) / s_N + v, (-1, 1))
+                lpd = -0.5 * (y_star - mu) ** 2 / y_s2 - 0.5 * np.log(2 * np.pi * y_s2)
+        if return_lpd:
+            return mu, s2, lpd
+        return mu, s2
+
+    # ------------------------------------------------------------------ misc
+    def _convert_shapes(self, X, y, s2):
+        """Reference :2523-2565."""
+        if X is None and y is None and s2 is None:
+            return X, y, s2
+        if X is not None:
+            if X.ndim == 1:
+                X = X[None, :]
+            if X.ndim != 2:
+                raise AssertionError("X need to be an array of shape (N, D)")
+            N, D = X.shape
+            if D != self.D:
+                raise AssertionError(
+                    f"The dimension of input data {D}doesn't match GP's input dimension {self.D}.")
+        else:
+            try:
+                N, D = self.X.shape
+            except AttributeError:
+                raise AttributeError(f"self.X is not a numpy array, self.X = {self.X}")
+        if y is not None:
+            y = y.reshape(N, 1)
+        if isinstance(s2, (float, int)):
+            s2 = s2 * np.ones((N, 1))
+        elif isinstance(s2, np.ndarray):
+            s2 = s2.reshape(N, 1)
+        elif s2 is not None:
+            raise TypeError("s2 type need to be Union[np.ndarray, float, int, None].")
+        return X, y, s2
+
+    def __str__(self):
+        cov_N, noise_N, mean_N = self._counts()
+        cov = "Covariance function: " + self.covariance.__class__.__name__
+        if self.covariance.__class__.__name__ == "Matern":
+            cov += "(degree=" + str(self.covariance.degree) + ")"
+        body = (
+            "Dimension: " + str(self.D) + "\n"
+            + cov + ", " + str(cov_N) + (" parameter\n" if cov_N == 1 else " parameters\n")
+            + "Mean function: " + self.mean.__class__.__name__ + ", " + str(mean_N)
+            + (" parameter\n" if mean_N == 1 else " parameters\n")
+            + "Noise function: " + self.noise.__class__.__name__ + ", " + str(noise_N)
+            + (" parameter\n" if noise_N == 1 else " parameters\n")
+            + "Hyperparameter priors: " + ("none\n" if self.no_prior else "present\n")
+            + "Hyperparameter samples: "
+            + ("0" if self.posteriors is None else str(np.size(self.posteriors)))
+        )
+        return "GP:\n" + indent(body, "    ")
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self._drop_handle()
+        except Exception:
+            pass

@@ -1,0 +1,127 @@
+"""CPU-side checks of the drop-in boundary: the shared library builds, loads, exports
+every symbol include/gpcore.h declares, and the product path fails loudly without a GPU."""
+
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _has_gpu():
+    return os.path.exists("/dev/kfd")
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+
+    ge.build()
+    from gpyreg_amd import _lib
+
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "gpcore.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(gpc_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_cov_count_entry_point_without_gpu():
+    from gpyreg_amd import _lib
+
+    lib = _lib.load()
+    assert lib.gpc_cov_count(_lib.K_SE, 5) == 6
+    assert lib.gpc_cov_count(_lib.K_RQ, 5) == 7
+    assert lib.gpc_cov_count(_lib.K_MATERN_ISO, 5) == 2
+    assert lib.gpc_cov_count(99, 5) == -1
+
+
+@pytest.mark.skipif(_has_gpu(), reason="only meaningful on a box without a GPU")
+def test_product_path_fails_loudly_without_gpu():
+    import gpyreg_amd as gpr
+
+    cov = gpr.covariance_functions.SquaredExponential()
+    with pytest.raises(RuntimeError) as e:
+        cov.compute(np.zeros(3), np.zeros((4, 2)))
+    assert "no CPU fallback" in str(e.value)
+    gp = gpr.GP(2, cov, gpr.mean_functions.ConstantMean(), gpr.noise_functions.GaussianNoise(constant_add=True))
+    with pytest.raises(RuntimeError):
+        gp.update(X_new=np.zeros((4, 2)), y_new=np.zeros(4), hyp=np.zeros((1, 5)))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "gpyreg_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("no CPU fallback", ""), os.path.join(dirpath, f)
+
+
+def test_mean_and_noise_plugins_match_golden_semantics(core_golden):
+    """The host-evaluated boundary plugins (mean/noise) against the oracle (itself pinned
+    bit-exactly to the reference): values, gradients, scalar-vs-array return."""
+    import gpyreg_amd as gpr
+    from conftest import parse_core_name
+    from oracle import gp_oracle as orc
+
+    g = core_golden
+    means = {"zero": gpr.mean_functions.ZeroMean, "const": gpr.mean_functions.ConstantMean,
+             "negquad": gpr.mean_functions.NegativeQuadratic}
+    for name in g["names"]:
+        tag, model, N, D, _ = parse_core_name(name)
+        X, y, hyp = g[tag + "_X"], g[tag + "_y"], g[tag + "_hyp"][0]
+        s2 = g[tag + "_s2"] if tag + "_s2" in g.files else None
+        cov_N = orc.cov_count(model["kernel"], D)
+        noise_N = orc.noise_count(model["noise"])
+        p = model["noise"]
+        noise = gpr.noise_functions.GaussianNoise(p[0] == 1, p[1] >= 1, p[1] == 2, p[2] == 1)
+        assert noise.hyperparameter_count() == noise_N
+        a, da = noise.compute(hyp[cov_N:cov_N + noise_N], X, y, s2, compute_grad=True)
+        b, db = orc.noise(p, hyp[cov_N:cov_N + noise_N], X, y, s2, compute_grad=True)
+        assert np.isscalar(a) == np.isscalar(b) and np.array_equal(a, b) and np.array_equal(da, db)
+        mean = means[model["mean"]]()
+        m, dm = mean.compute(hyp[cov_N + noise_N:], X, compute_grad=True)
+        rm, rdm = orc.mean(model["mean"], hyp[cov_N + noise_N:], X, compute_grad=True)
+        assert np.array_equal(m, rm) and np.array_equal(np.asarray(dm), np.asarray(rdm))
+
+
+def test_plugin_validation_messages():
+    import gpyreg_amd as gpr
+
+    X = np.ones((5, 2))
+    with pytest.raises(ValueError) as e:
+        gpr.mean_functions.ConstantMean().compute(np.ones(3), X)
+    assert "Expected 1 mean function hyperparameters" in e.value.args[0]
+    with pytest.raises(ValueError) as e:
+        gpr.mean_functions.NegativeQuadratic().compute(np.ones((5, 1)), X)
+    assert "Mean function output is available only for" in e.value.args[0]
+    with pytest.raises(ValueError) as e:
+        gpr.noise_functions.GaussianNoise(constant_add=True).compute(np.ones(2), X, None)
+    assert "Expected 1 noise function hyperparameters" in e.value.args[0]
+    with pytest.raises(ValueError) as e:
+        gpr.noise_functions.GaussianNoise(constant_add=True).compute(np.ones((1, 1)), X, None)
+    assert "Noise function output is available only for" in e.value.args[0]
+
+
+def test_hyperparameter_dict_roundtrip_and_order():
+    import gpyreg_amd as gpr
+
+    gp = gpr.GP(3, gpr.covariance_functions.RationalQuadraticARD(), gpr.mean_functions.NegativeQuadratic(),
+                gpr.noise_functions.GaussianNoise(constant_add=True, user_provided_add=True, scale_user_provided=True))
+    n = 5 + 2 + 7
+    arr = np.arange(2 * n, dtype=float).reshape(2, n)
+    d = gp.hyperparameters_to_dict(arr)
+    assert list(d[0]) == ["covariance_log_lengthscale", "covariance_log_outputscale", "covariance_log_shape",
+                          "noise_log_scale", "noise_provided_log_multiplier", "mean_const", "mean_location",
+                          "mean_log_scale"]
+    assert np.array_equal(gp.hyperparameters_from_dict(d), arr)
+    with pytest.raises(ValueError):
+        gp.hyperparameters_to_dict(np.zeros((1, n + 1)))
+    assert np.isnan(gp.get_hyperparameters(as_array=True)).all()
+    gp.update(hyp=arr, compute_posterior=False)
+    assert np.array_equal(gp.get_hyperparameters(as_array=True), arr)

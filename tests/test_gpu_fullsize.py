@@ -1,0 +1,73 @@
+"""Full-size GPU checks at BASELINE.json's configurations through size-independent
+properties, plus the two full-size reference values SURVEY.md 8(d) recorded (they were
+produced by the reference itself at survey time)."""
+
+import numpy as np
+import pytest
+
+from oracle import gp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _gp(cfg):
+    import bench
+
+    return bench.make_gp(cfg, "f64")
+
+
+def test_cfg2_matches_survey_reference_value():
+    import bench
+
+    X, y, hyp = bench.synthetic_problem(2, 1)
+    # bench's generator and the oracle's agree
+    _, X2, y2, hyp2 = orc.synthetic_problem(2)
+    assert np.array_equal(X, X2) and np.array_equal(y, y2) and np.array_equal(hyp, hyp2)
+    gp = _gp(2)
+    gp.update(X_new=X, y_new=y, hyp=hyp, compute_posterior=False)
+    nlz, dnlz = gp.nll_batch(hyp, compute_grad=True)
+    assert abs(nlz[0] - (-1166.298896135079)) < 1e-8 * 1166.3
+
+
+def test_cfg3_reference_value_gradient_and_batch_consistency():
+    import bench
+
+    X, y, hyp = bench.synthetic_problem(3, 16)
+    gp = _gp(3)
+    gp.update(X_new=X, y_new=y, hyp=hyp[:1], compute_posterior=False)
+    nlz, dnlz = gp.nll_batch(hyp, compute_grad=True)
+    assert abs(nlz[0] - 486.629241506640) < 1e-8 * 486.63  # reference value, SURVEY 8(d)
+    assert abs(nlz[1] - 702.291395297840) < 1e-8 * 702.29
+    assert np.isfinite(dnlz).all()
+    # batch of 16 == one at a time (no cross-talk between samples), NLL-only == with grad
+    n1, d1 = gp.nll_batch(hyp[5:6], compute_grad=True)
+    assert n1[0] == nlz[5] and np.array_equal(d1[0], dnlz[5])
+    n0, _ = gp.nll_batch(hyp[:4], compute_grad=False)
+    assert np.allclose(n0, nlz[:4], rtol=1e-13)
+    # directional derivative: central difference along a random direction
+    rng = np.random.default_rng(0)
+    v = rng.standard_normal(hyp.shape[1])
+    v /= np.linalg.norm(v)
+    eps = 1e-5
+    pm, _ = gp.nll_batch(np.stack([hyp[0] + eps * v, hyp[0] - eps * v]))
+    num = (pm[0] - pm[1]) / (2 * eps)
+    assert abs(num - dnlz[0] @ v) < 1e-6 * max(1.0, abs(num))
+
+
+def test_predict_interpolates_at_full_size():
+    import bench
+
+    X, y, hyp = bench.synthetic_problem(2, 2)
+    gp = _gp(2)
+    gp.update(X_new=X, y_new=y, hyp=hyp)
+    mu, s2 = gp.predict(X[:300], separate_samples=True)
+    # posterior variance at training inputs is below the prior variance and non-negative,
+    # the mean tracks the targets to within a few noise standard deviations
+    sf2 = np.exp(2 * hyp[:, 5])
+    assert (s2 >= 0).all() and (s2 < sf2[None, :]).all()
+    assert np.abs(mu - y[:300]).max() < 1.0
+    # alpha reproduces the data equation  (K + sn2 I) alpha = y - m  through predict:
+    # mean at training points = y - sn2 * alpha
+    a = gp.posteriors[0].alpha[:300, 0]
+    sn2 = np.exp(2 * hyp[0, 6])
+    assert np.allclose(mu[:, 0], y[:300, 0] - sn2 * a, rtol=1e-7, atol=1e-8)

@@ -1,0 +1,114 @@
+"""world_size-2 CPU (gloo) test of the multi-GPU path: sample sharding + all-gather.
+
+The device evaluator is replaced by a stand-in that calls the CPU oracle (tests may);
+what is under test is gpyreg_amd.sharding: partition, padding of unequal shards, the
+all-gather and the reassembly order."""
+
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _OracleGP:
+    """Quacks like gpyreg_amd.GP.nll_batch / predict, computed by the oracle."""
+
+    def __init__(self, model, X, y):
+        self.model, self.X, self.y = model, X, y
+        self.calls = []
+        self.posts = None
+
+    def nll_batch(self, hyp, compute_grad=False):
+        from oracle import gp_oracle as orc
+
+        self.calls.append(hyp.shape[0])
+        nl, dn = [], []
+        for h in hyp:
+            r = orc.core(self.model, h, self.X, self.y, None, 1, 1 if compute_grad else 0)
+            nl.append(r[0] if compute_grad else r)
+            if compute_grad:
+                dn.append(r[1])
+        return np.array(nl), (np.stack(dn) if compute_grad else None)
+
+    def predict(self, xs, separate_samples=True):
+        from oracle import gp_oracle as orc
+
+        return orc.predict(self.model, self.posts, self.X, self.y, xs, separate_samples=True)
+
+
+def _worker(rank, world, port, S, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    from gpyreg_amd import sharding
+    from oracle import gp_oracle as orc
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model, X, y, hyp = orc.synthetic_problem(2, N=60, D=2, S=S)
+        gp = _OracleGP(model, X, y)
+        nlz, dnlz = sharding.nll_batch_sharded(gp, hyp, compute_grad=True)
+        nlz0, none = sharding.nll_batch_sharded(gp, hyp, compute_grad=False)
+        lo, hi = sharding.shard_bounds(S, rank, world)
+        gp.posts = orc.posteriors(model, hyp[lo:hi], X, y, None)
+        mu, s2 = sharding.predict_sharded(gp, X[:5])
+        q.put((rank, nlz, dnlz, nlz0, none is None, gp.calls, mu, s2))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("S", [5, 4])
+def test_sharded_nll_and_predict_world2(S):
+    import torch.multiprocessing as mp
+
+    from gpyreg_amd import sharding
+    from oracle import gp_oracle as orc
+
+    assert [sharding.shard_bounds(5, r, 2) for r in range(2)] == [(0, 3), (3, 5)]
+    assert [sharding.shard_bounds(16, r, 8) for r in range(8)][-1] == (14, 16)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, S, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    model, X, y, hyp = orc.synthetic_problem(2, N=60, D=2, S=S)
+    ref = [orc.core(model, h, X, y, None, 1, 1) for h in hyp]
+    ref_n = np.array([r[0] for r in ref])
+    ref_d = np.stack([r[1] for r in ref])
+    posts = orc.posteriors(model, hyp, X, y, None)
+    rmu, rs2 = orc.predict(model, posts, X, y, X[:5], separate_samples=True)
+    for rank, nlz, dnlz, nlz0, none_ok, calls, mu, s2 in res:
+        assert np.array_equal(nlz, ref_n) and np.array_equal(dnlz, ref_d)  # every rank has it all
+        assert np.array_equal(nlz0, ref_n) and none_ok
+        lo, hi = sharding.shard_bounds(S, rank, 2)
+        assert calls == [hi - lo, hi - lo]  # each rank evaluated only its own block
+        assert np.array_equal(mu, rmu) and np.array_equal(s2, rs2)
+
+
+def test_single_process_passthrough():
+    from gpyreg_amd import sharding
+    from oracle import gp_oracle as orc
+
+    model, X, y, hyp = orc.synthetic_problem(2, N=30, D=2, S=3)
+    gp = _OracleGP(model, X, y)
+    nlz, dnlz = sharding.nll_batch_sharded(gp, hyp, compute_grad=True)
+    assert gp.calls == [3] and nlz.shape == (3,) and dnlz.shape == (3, 5)

@@ -1,0 +1,21 @@
+#!/bin/bash
+# usage (on the GPU box, from the repo root): bash tools_gpu_run.sh <tag> [steps]
+# runs: GPU tests -> smoke -> bench -> rocprofv3 kernel trace of the bench; logs under gpurun_out/<tag>/
+set -o pipefail
+TAG=${1:-run}; STEPS=${2:-5}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/$TAG; mkdir -p $O
+cd $R
+(timeout -k 10 700 python -m pytest tests -m gpu -q -s -p no:cacheprovider > $O/tests.log 2>&1; rc=$?; echo "pytest exit=$rc" >> $O/tests.log; tail -3 $O/tests.log; [ $rc -eq 0 -o $rc -eq 1 ]) \
+&& (timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; rc=$?; echo "smoke exit=$rc" >> $O/smoke.log; tail -2 $O/smoke.log; [ $rc -eq 0 -o $rc -eq 1 ]) \
+&& (timeout -k 10 400 python bench.py --steps $STEPS --warmup 2 > $O/bench.json 2> $O/bench.err; rc=$?; echo "bench exit=$rc"; cat $O/bench.json; tail -3 $O/bench.err; [ $rc -eq 0 -o $rc -eq 1 ]) \
+&& (cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/prof.log 2>&1; rc=$?; echo "rocprof exit=$rc"; tail -2 $O/prof.log; find $O/prof -name "*stats*" | head)
+# optional third arg "pmc": hardware-counter passes (own runs, kernel-trace only)
+if [ "$3" = "pmc" ]; then
+  cd /tmp && export TMPDIR=/tmp
+  rocprofv3 -L > $O/counters_list.txt 2>&1
+  timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $O/pmc1 -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc1.log 2>&1; echo "pmc1 exit=$?"
+  timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE TCC_HIT_sum --kernel-trace --output-format csv -d $O/pmc2 -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc2.log 2>&1; echo "pmc2 exit=$?"
+  timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE TCC_MISS_sum GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc3 -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc3.log 2>&1; echo "pmc3 exit=$?"
+  find $O -name "*counter_collection*" | head
+fi
