@@ -212,11 +212,12 @@ class Context:
 
     # ---- test hooks -------------------------------------------------------------
     def debug_gemm(self, A, B, Cm, M, N, K, a_kmajor, b_kmajor, alpha=1.0, beta=0, klo=0, khi=0,
-                   lower_only=False, dtype=F64):
+                   lower_only=False, dtype=F64, force_bt=0):
         A, B = _f64(A), _f64(B)
         Cm = _f64(Cm).copy()
+        flags = int(bool(lower_only)) | {0: 0, 64: 0x100, 128: 0x200}[force_bt]
         rc = self._lib.gpc_debug_gemm(self._h, dtype, M, N, K, int(a_kmajor), int(b_kmajor),
-                                      float(alpha), int(beta), klo, khi, int(lower_only), _ptr(A),
+                                      float(alpha), int(beta), klo, khi, flags, _ptr(A),
                                       _ptr(B), _ptr(Cm))
         self._check(rc, "gpc_debug_gemm")
         return Cm

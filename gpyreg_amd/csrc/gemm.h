@@ -10,6 +10,7 @@
 // Design (CDNA4, 64-wide waves):
 //   * block tile 128 x 128, 256 threads = 4 waves, each wave a 64 x 64 sub-tile held
 //     as 4 x 4 accumulators of v_mfma_f64_16x16x4_f64 (or the f32 form): 128 VGPRs.
+//     (A 64 x 64 variant serves launches too small to fill the chip.)
 //   * operands are staged global -> registers -> LDS in k-slabs of 16, double
 //     buffered, one barrier per slab; the next slab's global loads are issued before
 //     the current slab's MFMAs so HBM/L2 latency hides under 64 MFMAs per wave.
@@ -26,10 +27,11 @@
 
 namespace gpc {
 
-constexpr int BKT = 16;          // k-slab per LDS stage
-constexpr int LDQ = BKT + 1;     // stride of an m-major LDS image  [128][17]
-constexpr int LDP = TILE + 16;   // stride of a  k-major LDS image  [16][144]
-constexpr int OPSZ = BKT * LDP;  // elements reserved per operand per stage (>= 128*17)
+constexpr int BKT = 16;       // k-slab per LDS stage
+constexpr int LDQ = BKT + 1;  // stride of an m-major LDS image  [BT][17]
+// stride of a k-major LDS image [16][BT+16]; elements reserved per operand per stage
+constexpr int ldp_of(int BT) { return BT + 16; }
+constexpr int opsz_of(int BT) { return BKT * (BT + 16) > BT * LDQ ? BKT * (BT + 16) : BT * LDQ; }
 
 enum { KLO_ZERO = 0, KLO_ROW = 1, KLO_COL = 2 };  // k0 = 0 | ti*128 | tj*128
 enum { KHI_FULL = 0, KHI_ROW = 1, KHI_COL = 2 };  // k1 = K | (ti+1)*128 | (tj+1)*128
@@ -47,12 +49,12 @@ struct GemmArgs {
   int tiles_m, tiles_n;
 };
 
-template <typename T, bool KM>
-__device__ __forceinline__ void g2r(typename MM<T>::vec_t (&r)[(TILE * BKT) / (256 * MM<T>::VEC)],
+template <typename T, bool KM, int BT>
+__device__ __forceinline__ void g2r(typename MM<T>::vec_t (&r)[(BT * BKT) / (256 * MM<T>::VEC)],
                                     const T* __restrict__ g, int ld, int r0, int k0, int t) {
   using vec_t = typename MM<T>::vec_t;
   constexpr int VEC = MM<T>::VEC;
-  constexpr int NV = (TILE * BKT) / (256 * VEC);
+  constexpr int NV = (BT * BKT) / (256 * VEC);
   if constexpr (!KM) {  // stored [row][k]
     constexpr int TPR = BKT / VEC;   // threads per row
     constexpr int RPP = 256 / TPR;   // rows per pass
@@ -63,7 +65,7 @@ __device__ __forceinline__ void g2r(typename MM<T>::vec_t (&r)[(TILE * BKT) / (2
       r[p] = *reinterpret_cast<const vec_t*>(g + (size_t)(r0 + row) * ld + k0 + kc);
     }
   } else {  // stored [k][row]
-    constexpr int VPR = TILE / VEC;  // vectors per k-row
+    constexpr int VPR = BT / VEC;  // vectors per k-row
 #pragma unroll
     for (int p = 0; p < NV; ++p) {
       const int v = t + 256 * p;
@@ -74,13 +76,14 @@ __device__ __forceinline__ void g2r(typename MM<T>::vec_t (&r)[(TILE * BKT) / (2
   }
 }
 
-template <typename T, bool KM>
+template <typename T, bool KM, int BT>
 __device__ __forceinline__ void r2s(T* __restrict__ s,
-                                    const typename MM<T>::vec_t (&r)[(TILE * BKT) / (256 * MM<T>::VEC)],
+                                    const typename MM<T>::vec_t (&r)[(BT * BKT) / (256 * MM<T>::VEC)],
                                     int t) {
   using vec_t = typename MM<T>::vec_t;
   constexpr int VEC = MM<T>::VEC;
-  constexpr int NV = (TILE * BKT) / (256 * VEC);
+  constexpr int NV = (BT * BKT) / (256 * VEC);
+  constexpr int LDP = ldp_of(BT);
   if constexpr (!KM) {
     constexpr int TPR = BKT / VEC;
     constexpr int RPP = 256 / TPR;
@@ -92,7 +95,7 @@ __device__ __forceinline__ void r2s(T* __restrict__ s,
       for (int e = 0; e < VEC; ++e) s[row * LDQ + kc + e] = r[p][e];
     }
   } else {
-    constexpr int VPR = TILE / VEC;
+    constexpr int VPR = BT / VEC;
 #pragma unroll
     for (int p = 0; p < NV; ++p) {
       const int v = t + 256 * p;
@@ -103,12 +106,12 @@ __device__ __forceinline__ void r2s(T* __restrict__ s,
   }
 }
 
-template <typename T, bool KM>
+template <typename T, bool KM, int BT>
 __device__ __forceinline__ T frag(const T* __restrict__ s, int r0, int kk, int lane) {
   if constexpr (!KM)
     return s[(r0 + (lane & 15)) * LDQ + kk + (lane >> 4)];
   else
-    return s[(kk + (lane >> 4)) * LDP + r0 + (lane & 15)];
+    return s[(kk + (lane >> 4)) * ldp_of(BT) + r0 + (lane & 15)];
 }
 
 __device__ __forceinline__ void tri_tile(int tile, int& ti, int& tj) {
@@ -119,11 +122,16 @@ __device__ __forceinline__ void tri_tile(int tile, int& ti, int& tj) {
   tj = tile - i * (i + 1) / 2;
 }
 
-template <typename T, bool AKM, bool BKM>
+// BT = block tile (128: 4 waves x 64x64; 64: 4 waves x 32x32, for launches too small to
+// fill 256 CUs with 128-tiles).  Triangular k-ranges stay 128-granular in both.
+template <typename T, bool AKM, bool BKM, int BT>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   using acc_t = typename MM<T>::acc_t;
   using vec_t = typename MM<T>::vec_t;
-  constexpr int NV = (TILE * BKT) / (256 * MM<T>::VEC);
+  constexpr int NV = (BT * BKT) / (256 * MM<T>::VEC);
+  constexpr int OPSZ = opsz_of(BT);
+  constexpr int WT = BT / 2;   // wave tile
+  constexpr int MR = BT / 32;  // 16x16 MFMA tiles per wave per dimension
   __shared__ __attribute__((aligned(16))) T smem[4 * OPSZ];
 
   const int t = threadIdx.x;
@@ -150,9 +158,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     ti = bx / g.tiles_n;
     tj = bx % g.tiles_n;
   }
-  const int m0 = ti * TILE, n0 = tj * TILE;
-  int k0 = g.klo == KLO_ROW ? m0 : (g.klo == KLO_COL ? n0 : 0);
-  int k1 = g.khi == KHI_ROW ? m0 + TILE : (g.khi == KHI_COL ? n0 + TILE : g.K);
+  const int m0 = ti * BT, n0 = tj * BT;
+  const int m128 = (m0 / TILE) * TILE, n128 = (n0 / TILE) * TILE;
+  int k0 = g.klo == KLO_ROW ? m128 : (g.klo == KLO_COL ? n128 : 0);
+  int k1 = g.khi == KHI_ROW ? m128 + TILE : (g.khi == KHI_COL ? n128 + TILE : g.K);
   if (k1 > g.K) k1 = g.K;
   const int nk = (k1 - k0) / BKT;
 
@@ -160,18 +169,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   const T* __restrict__ B = reinterpret_cast<const T*>(g.B) + (size_t)blockIdx.y * g.sB;
   T* __restrict__ C = reinterpret_cast<T*>(g.C) + (size_t)blockIdx.y * g.sC;
 
-  acc_t acc[4][4];
+  acc_t acc[MR][MR];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MR; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+    for (int j = 0; j < MR; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
 
   if (nk > 0) {
     vec_t ra[NV], rb[NV];
-    g2r<T, AKM>(ra, A, g.lda, m0, k0, t);
-    g2r<T, BKM>(rb, B, g.ldb, n0, k0, t);
-    r2s<T, AKM>(smem, ra, t);
-    r2s<T, BKM>(smem + OPSZ, rb, t);
+    g2r<T, AKM, BT>(ra, A, g.lda, m0, k0, t);
+    g2r<T, BKM, BT>(rb, B, g.ldb, n0, k0, t);
+    r2s<T, AKM, BT>(smem, ra, t);
+    r2s<T, BKM, BT>(smem + OPSZ, rb, t);
     __syncthreads();
     for (int it = 0; it < nk; ++it) {
       const int cur = it & 1;
@@ -179,25 +188,25 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
       const T* b_s = a_s + OPSZ;
       const bool more = (it + 1 < nk);
       if (more) {
-        g2r<T, AKM>(ra, A, g.lda, m0, k0 + (it + 1) * BKT, t);
-        g2r<T, BKM>(rb, B, g.ldb, n0, k0 + (it + 1) * BKT, t);
+        g2r<T, AKM, BT>(ra, A, g.lda, m0, k0 + (it + 1) * BKT, t);
+        g2r<T, BKM, BT>(rb, B, g.ldb, n0, k0 + (it + 1) * BKT, t);
       }
 #pragma unroll
       for (int kk = 0; kk < BKT; kk += 4) {
-        T af[4], bf[4];
+        T af[MR], bf[MR];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = frag<T, AKM>(a_s, wr * 64 + i * 16, kk, lane);
+        for (int i = 0; i < MR; ++i) af[i] = frag<T, AKM, BT>(a_s, wr * WT + i * 16, kk, lane);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bf[j] = frag<T, BKM>(b_s, wc * 64 + j * 16, kk, lane);
+        for (int j = 0; j < MR; ++j) bf[j] = frag<T, BKM, BT>(b_s, wc * WT + j * 16, kk, lane);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MR; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = MM<T>::mma(af[i], bf[j], acc[i][j]);
+          for (int j = 0; j < MR; ++j) acc[i][j] = MM<T>::mma(af[i], bf[j], acc[i][j]);
       }
       if (more) {
         T* a_n = smem + (cur ^ 1) * 2 * OPSZ;
-        r2s<T, AKM>(a_n, ra, t);
-        r2s<T, BKM>(a_n + OPSZ, rb, t);
+        r2s<T, AKM, BT>(a_n, ra, t);
+        r2s<T, BKM, BT>(a_n + OPSZ, rb, t);
       }
       __syncthreads();
     }
@@ -205,13 +214,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 
   const T alpha = (T)g.alpha;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MR; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < MR; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wr * 64 + i * 16 + MM<T>::row_of(lane, r);
-        const int col = n0 + wc * 64 + j * 16 + (lane & 15);
+        const int row = m0 + wr * WT + i * 16 + MM<T>::row_of(lane, r);
+        const int col = n0 + wc * WT + j * 16 + (lane & 15);
         T* p = C + (size_t)row * g.ldc + col;
         T v = alpha * acc[i][j][r];
         if (g.beta) v += *p;
@@ -219,23 +228,36 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
       }
 }
 
-template <typename T>
-inline hipError_t launch_gemm(hipStream_t st, GemmArgs g, bool akm, bool bkm, int batch) {
-  const int tm = g.M / TILE, tn = g.N / TILE;
+template <typename T, int BT>
+inline hipError_t launch_gemm_bt(hipStream_t st, GemmArgs g, bool akm, bool bkm, int batch) {
+  const int tm = g.M / BT, tn = g.N / BT;
   g.tiles_m = tm;
   g.tiles_n = tn;
   const int ntiles = g.lower_only ? tm * (tm + 1) / 2 : tm * tn;
   if (ntiles <= 0 || batch <= 0) return hipSuccess;
   dim3 grid(ntiles, batch), block(256);
   if (!akm && !bkm)
-    hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, block, 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<T, false, false, BT>), grid, block, 0, st, g);
   else if (!akm && bkm)
-    hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, block, 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<T, false, true, BT>), grid, block, 0, st, g);
   else if (akm && bkm)
-    hipLaunchKernelGGL((gemm_kernel<T, true, true>), grid, block, 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<T, true, true, BT>), grid, block, 0, st, g);
   else
-    hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, block, 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<T, true, false, BT>), grid, block, 0, st, g);
   return hipGetLastError();
+}
+
+// Launches that cannot put ~2 blocks of 128-tiles on every CU use 64-tiles (4x the blocks,
+// a quarter of the work each): the deep levels of the recursion are latency-, not
+// throughput-bound.  force_bt: 0 = choose, 64 / 128 = as given (tests).
+constexpr int SMALL_LAUNCH_BLOCKS = 768;
+template <typename T>
+inline hipError_t launch_gemm(hipStream_t st, GemmArgs g, bool akm, bool bkm, int batch, int force_bt = 0) {
+  const int tm = g.M / TILE, tn = g.N / TILE;
+  const long long blocks128 = (long long)(g.lower_only ? tm * (tm + 1) / 2 : tm * tn) * batch;
+  const bool small = force_bt ? (force_bt == 64) : (blocks128 < SMALL_LAUNCH_BLOCKS);
+  if (small) return launch_gemm_bt<T, 64>(st, g, akm, bkm, batch);
+  return launch_gemm_bt<T, 128>(st, g, akm, bkm, batch);
 }
 
 // algorithmic flops of one launch (for the roofline bookkeeping)

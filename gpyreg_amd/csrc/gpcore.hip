@@ -723,9 +723,9 @@ int debug_gemm_impl(gpc_ctx* c, int M, int N, int K, int akm, int bkm, double al
   g.beta = beta;
   g.klo = klo;
   g.khi = khi;
-  g.lower_only = lower;
+  g.lower_only = lower & 1;
   g.tiles_n = N / TILE;
-  HIPCHK(c, launch_gemm<T>(c->st, g, akm != 0, bkm != 0, 1));
+  HIPCHK(c, launch_gemm<T>(c->st, g, akm != 0, bkm != 0, 1, (lower & 0x100) ? 64 : ((lower & 0x200) ? 128 : 0)));
   return download_as<T>(c, c->dbg3.as<T>(), C, (size_t)M * N);
 }
 
@@ -1081,7 +1081,7 @@ int gpc_debug_gemm(gpc_ctx* c, int dtype, int M, int N, int K, int a_kmajor, int
                    int beta, int klo, int khi, int lower_only, const double* A, const double* B, double* C) {
   if (!c) return -2;
   if (M % TILE || N % TILE || K % TILE || M <= 0 || N <= 0 || K <= 0) FAIL(c, "gpc_debug_gemm: sizes must be multiples of 128");
-  if (lower_only && M != N) FAIL(c, "gpc_debug_gemm: lower_only needs M == N");
+  if ((lower_only & 1) && M != N) FAIL(c, "gpc_debug_gemm: lower_only needs M == N");
   HIPCHK(c, hipSetDevice(c->device));
   return dtype == GPC_F64
              ? debug_gemm_impl<double>(c, M, N, K, a_kmajor, b_kmajor, alpha, beta, klo, khi, lower_only, A, B, C)

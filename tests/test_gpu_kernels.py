@@ -32,6 +32,7 @@ def _ref_gemm(A, B, C, M, N, K, akm, bkm, alpha, beta, klo, khi, lower, tile=128
     return out
 
 
+@pytest.mark.parametrize("bt", [128, 64])
 @pytest.mark.parametrize("akm,bkm", [(0, 0), (0, 1), (1, 1), (1, 0)])
 @pytest.mark.parametrize(
     "M,N,K,klo,khi,lower,alpha,beta",
@@ -45,18 +46,18 @@ def _ref_gemm(A, B, C, M, N, K, akm, bkm, alpha, beta, klo, khi, lower, tile=128
         (384, 384, 384, 1, 0, 1, 1.0, 0),    # lauum: k >= row tile, lower tiles
     ],
 )
-def test_gemm_modes_fp64(ctx, akm, bkm, M, N, K, klo, khi, lower, alpha, beta):
+def test_gemm_modes_fp64(ctx, bt, akm, bkm, M, N, K, klo, khi, lower, alpha, beta):
     rng = np.random.default_rng(M + 3 * N + 7 * K + 11 * klo + 13 * khi + akm * 17 + bkm * 19)
     A = rng.standard_normal((K, M) if akm else (M, K))
     B = rng.standard_normal((K, N) if bkm else (N, K))  # asymmetric operands on purpose
     C0 = rng.standard_normal((M, N))
-    got = ctx.debug_gemm(A, B, C0, M, N, K, akm, bkm, alpha, beta, klo, khi, lower)
+    got = ctx.debug_gemm(A, B, C0, M, N, K, akm, bkm, alpha, beta, klo, khi, lower, force_bt=bt)
     ref = _ref_gemm(A, B, C0, M, N, K, akm, bkm, alpha, beta, klo, khi, lower)
     mask = np.ones((M, N), bool)
-    if lower:
-        for ti in range(M // 128):
-            for tj in range(ti + 1, N // 128):
-                mask[ti * 128:(ti + 1) * 128, tj * 128:(tj + 1) * 128] = False
+    if lower:  # tiles strictly above the diagonal (in units of the kernel's tile) are skipped
+        for ti in range(M // bt):
+            for tj in range(ti + 1, N // bt):
+                mask[ti * bt:(ti + 1) * bt, tj * bt:(tj + 1) * bt] = False
     err = np.abs(got - ref)[mask].max()
     assert err < 1e-11 * max(1.0, np.abs(ref[mask]).max()), err
     # untouched tiles of a lower_only launch keep their input value
@@ -70,9 +71,12 @@ def test_gemm_fp32(ctx):
     rng = np.random.default_rng(5)
     M = N = K = 256
     A, B = rng.standard_normal((M, K)), rng.standard_normal((K, N))
-    got = ctx.debug_gemm(A, B, np.zeros((M, N)), M, N, K, 0, 1, dtype=_lib.F32)
     ref = A.astype(np.float32).astype(np.float64) @ B.astype(np.float32).astype(np.float64)
-    assert np.abs(got - ref).max() < 2e-4 * np.abs(ref).max()
+    for bt in (128, 64):
+        got = ctx.debug_gemm(A, B, np.zeros((M, N)), M, N, K, 0, 1, dtype=_lib.F32, force_bt=bt)
+        assert np.abs(got - ref).max() < 2e-4 * np.abs(ref).max()
+        got = ctx.debug_gemm(B.T.copy(), A.T.copy(), np.zeros((N, M)), N, M, K, 0, 1, dtype=_lib.F32, force_bt=bt)
+        assert np.abs(got - ref.T).max() < 2e-4 * np.abs(ref).max()
 
 
 def _spd(n, rng, noise=0.01, D=2):
