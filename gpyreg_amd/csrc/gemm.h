@@ -47,7 +47,10 @@ struct GemmArgs {
   int beta;  // 0 or 1
   int klo, khi, lower_only;
   int tiles_m, tiles_n;
+  int flags;  // experiment switches (GPC_GEMM_FLAGS): 1 setprio, 2 no restage (timing only),
+              // 4 no global loads (timing only)
 };
+inline int g_gemm_flags = 0;
 
 template <typename T, bool KM, int BT>
 __device__ __forceinline__ void g2r(typename MM<T>::vec_t (&r)[(BT * BKT) / (256 * MM<T>::VEC)],
@@ -187,10 +190,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
       const T* a_s = smem + cur * 2 * OPSZ;
       const T* b_s = a_s + OPSZ;
       const bool more = (it + 1 < nk);
-      if (more) {
+      if (more && !(g.flags & 4)) {
         g2r<T, AKM, BT>(ra, A, g.lda, m0, k0 + (it + 1) * BKT, t);
         g2r<T, BKM, BT>(rb, B, g.ldb, n0, k0 + (it + 1) * BKT, t);
       }
+      if (g.flags & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int kk = 0; kk < BKT; kk += 4) {
         T af[MR], bf[MR];
@@ -203,6 +207,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
           for (int j = 0; j < MR; ++j) acc[i][j] = MM<T>::mma(af[i], bf[j], acc[i][j]);
       }
+      if (g.flags & 1) __builtin_amdgcn_s_setprio(0);
+      if (g.flags & 2) continue;
       if (more) {
         T* a_n = smem + (cur ^ 1) * 2 * OPSZ;
         r2s<T, AKM, BT>(a_n, ra, t);
@@ -233,6 +239,7 @@ inline hipError_t launch_gemm_bt(hipStream_t st, GemmArgs g, bool akm, bool bkm,
   const int tm = g.M / BT, tn = g.N / BT;
   g.tiles_m = tm;
   g.tiles_n = tn;
+  g.flags = g_gemm_flags;
   const int ntiles = g.lower_only ? tm * (tm + 1) / 2 : tm * tn;
   if (ntiles <= 0 || batch <= 0) return hipSuccess;
   dim3 grid(ntiles, batch), block(256);
@@ -250,12 +257,12 @@ inline hipError_t launch_gemm_bt(hipStream_t st, GemmArgs g, bool akm, bool bkm,
 // Launches that cannot put ~2 blocks of 128-tiles on every CU use 64-tiles (4x the blocks,
 // a quarter of the work each): the deep levels of the recursion are latency-, not
 // throughput-bound.  force_bt: 0 = choose, 64 / 128 = as given (tests).
-constexpr int SMALL_LAUNCH_BLOCKS = 768;
+inline int g_small_launch_blocks = 1100;  // tunable: GPC_SMALL_BLOCKS
 template <typename T>
 inline hipError_t launch_gemm(hipStream_t st, GemmArgs g, bool akm, bool bkm, int batch, int force_bt = 0) {
   const int tm = g.M / TILE, tn = g.N / TILE;
   const long long blocks128 = (long long)(g.lower_only ? tm * (tm + 1) / 2 : tm * tn) * batch;
-  const bool small = force_bt ? (force_bt == 64) : (blocks128 < SMALL_LAUNCH_BLOCKS);
+  const bool small = force_bt ? (force_bt == 64) : (blocks128 < g_small_launch_blocks);
   if (small) return launch_gemm_bt<T, 64>(st, g, akm, bkm, batch);
   return launch_gemm_bt<T, 128>(st, g, akm, bkm, batch);
 }
