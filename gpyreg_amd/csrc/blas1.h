@@ -10,25 +10,49 @@ namespace gpc {
 // z[b][i] = sum_{k<=i} W[b][i][k] * r[b][k].   One wave per row, 4 rows per block.
 // The diagonal tile of W is zero above the diagonal, so the row is read up to the end
 // of its 128-wide diagonal tile without masking.   grid = (npad/4, batch)
+// With row0 > 0 the product is restricted to the diagonal block starting at row0
+// (rows row0 + blockIdx.x*4 + wave, columns >= row0): the blocked forward solve.
 template <typename T>
 __global__ __launch_bounds__(256) void trmv_kernel(const T* __restrict__ W_all, long long sW, int ldw,
                                                    const double* __restrict__ r_all, int npad,
-                                                   double* __restrict__ z_all) {
+                                                   double* __restrict__ z_all, int row0) {
   using vec_t = typename MM<T>::vec_t;
   constexpr int VEC = MM<T>::VEC;
   const int b = blockIdx.y, lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int i = row0 + blockIdx.x * 4 + (threadIdx.x >> 6);
   const T* Wr = W_all + (size_t)b * sW + (size_t)i * ldw;
   const double* r = r_all + (size_t)b * npad;
   const int kend = ((i >> 7) + 1) << 7;
   double s = 0.0;
-  for (int k = lane * VEC; k < kend; k += 64 * VEC) {
+  for (int k = row0 + lane * VEC; k < kend; k += 64 * VEC) {
     const vec_t wv = *reinterpret_cast<const vec_t*>(Wr + k);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) s += (double)wv[e] * r[k + e];
   }
   s = wave_sum(s);
   if (lane == 0) z_all[(size_t)b * npad + i] = s;
+}
+
+// r[b][row0 + i] -= sum_{k < ncols} A[b][row0 + i][col0 + k] * z[b][col0 + k]
+// (the off-diagonal update of the blocked forward solve).  grid = (nrows/4, batch)
+template <typename T>
+__global__ __launch_bounds__(256) void gemv_sub_kernel(const T* __restrict__ A_all, long long sA, int lda,
+                                                       const double* __restrict__ z_all, double* __restrict__ r_all,
+                                                       int npad, int row0, int col0, int ncols) {
+  using vec_t = typename MM<T>::vec_t;
+  constexpr int VEC = MM<T>::VEC;
+  const int b = blockIdx.y, lane = threadIdx.x & 63;
+  const int i = row0 + blockIdx.x * 4 + (threadIdx.x >> 6);
+  const T* Ar = A_all + (size_t)b * sA + (size_t)i * lda + col0;
+  const double* z = z_all + (size_t)b * npad + col0;
+  double s = 0.0;
+  for (int k = lane * VEC; k < ncols; k += 64 * VEC) {
+    const vec_t av = *reinterpret_cast<const vec_t*>(Ar + k);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s += (double)av[e] * z[k + e];
+  }
+  s = wave_sum(s);
+  if (lane == 0) r_all[(size_t)b * npad + i] -= s;
 }
 
 // out[b][k] = scale[b] * sum_{i>=k} W[b][i][k] * z[b][i]   (W^T z).  grid = (npad/64, batch)

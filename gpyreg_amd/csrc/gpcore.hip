@@ -283,16 +283,17 @@ struct Pipe {
     F.sA = F.sW = F.sT = sM;
     F.logdet = d_logdet;
     F.info = d_info;
-    F.potrf_inv(0, npad, true, mode == MODE_POST);
+    // NLL only: the inverse of the whole matrix is not needed (only of left children)
+    const bool full_inv = (mode != MODE_NLL);
+    F.potrf_inv(0, npad, full_inv, mode == MODE_POST);
     if (mode == MODE_GRAD) F.lauum(Tc, sM);
     HIPCHK(c, F.err);
     HIPCHK(c, hipGetLastError());
     if (f1) HIPCHK(c, hipEventRecord(f1, st));
     c->last_flops += F.flops;
 
-    // z = W r ; quad = z.z ; alpha = W^T z / sl
-    hipLaunchKernelGGL((trmv_kernel<T>), dim3(npad / 4, n), dim3(256), 0, st, (const T*)Wc, sM, npad,
-                       (const double*)rvec, npad, zvec);
+    // z = L^-1 r ; quad = z.z ; alpha = W^T z / sl
+    F.forward_solve(0, npad, full_inv, rvec, zvec);
     hipLaunchKernelGGL(dot_kernel, dim3(1, n), dim3(256), 0, st, (const double*)zvec, (const double*)zvec,
                        npad, npad, d_quad);
     if (mode != MODE_NLL) {

@@ -98,6 +98,25 @@ struct Factor {
     }
   }
 
+  // z = L^-1 r after potrf_inv(.., need_inv): blocks that own their full inverse multiply
+  // by W, the others split like the factorization and eliminate with L21 (kept in A for
+  // exactly those blocks).  r is consumed (updated in place); r, z: [batch][npad] doubles.
+  void forward_solve(int off, int n, bool need_inv, double* r, double* z) {
+    if (need_inv || n == TILE) {
+      hipLaunchKernelGGL((trmv_kernel<T>), dim3(n / 4, batch), dim3(256), 0, st, (const T*)W, sW, npad,
+                         (const double*)r, npad, z, off);
+      ++launches;
+      return;
+    }
+    const int q = n / TILE;
+    const int n1 = (q / 2) * TILE, n2 = n - n1;
+    forward_solve(off, n1, true, r, z);
+    hipLaunchKernelGGL((gemv_sub_kernel<T>), dim3(n2 / 4, batch), dim3(256), 0, st, (const T*)A, sA, npad,
+                       (const double*)z, r, npad, off + n1, off, n1);
+    ++launches;
+    forward_solve(off + n1, n2, need_inv, r, z);
+  }
+
   // Ainv (lower tiles, into `out`) = W^T W
   void lauum(T* out, long long sOut) {
     gemm(out, sOut, W, sW, W, sW, npad, npad, npad, true, true, 1.0, 0, KLO_ROW, KHI_FULL, 1);

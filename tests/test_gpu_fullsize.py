@@ -71,3 +71,27 @@ def test_predict_interpolates_at_full_size():
     a = gp.posteriors[0].alpha[:300, 0]
     sn2 = np.exp(2 * hyp[0, 6])
     assert np.allclose(mu[:, 0], y[:300, 0] - sn2 * a, rtol=1e-7, atol=1e-8)
+
+
+def test_fp32_mode_within_1e3_of_fp64():
+    """north_star: fp32 factorization within 1e-3 relative of the fp64 result."""
+    import bench
+
+    for cfg, N in [(4, 2048), (3, 1024)]:
+        bench_cfg = dict(bench.CONFIGS[cfg])
+        try:
+            bench.CONFIGS[cfg] = dict(bench_cfg, N=N)
+            X, y, hyp = bench.synthetic_problem(cfg, 3)
+            res = {}
+            for dt in ("f64", "f32"):
+                gp = bench.make_gp(cfg, dt)
+                gp.update(X_new=X, y_new=y, hyp=hyp)
+                res[dt] = gp.nll_batch(hyp, compute_grad=True) + gp.predict(X[:50], separate_samples=True)
+        finally:
+            bench.CONFIGS[cfg] = bench_cfg
+        n64, d64, mu64, s64 = res["f64"]
+        n32, d32, mu32, s32 = res["f32"]
+        assert np.abs(n32 - n64).max() <= 1e-3 * np.abs(n64).max()
+        assert (np.abs(d32 - d64) / np.maximum(np.abs(d64), np.abs(d64).max(1, keepdims=True))).max() <= 1e-3
+        assert np.abs(mu32 - mu64).max() <= 1e-3 * max(1.0, np.abs(mu64).max())
+        assert np.abs(s32 - s64).max() <= 1e-3
