@@ -217,4 +217,27 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(T* out, int iters, long 
   out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// independent-chain VALU FMA loop (what the non-MFMA kernels are bounded by)
+template <typename T>
+__global__ __launch_bounds__(256) void valu_peak_kernel(T* out, int iters, long long* clk) {
+  T acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = (T)(threadIdx.x + i);
+  const T a = (T)(1.0 + threadIdx.x * 1e-9), bq = (T)(threadIdx.x * 1e-7);
+  const long long c0 = clock64(), w0 = wall_clock64();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = acc[i] * a + bq;
+  }
+  const long long c1 = clock64(), w1 = wall_clock64();
+  if (clk && blockIdx.x == 0 && threadIdx.x == 0) {
+    clk[0] = c1 - c0;
+    clk[1] = w1 - w0;
+  }
+  T s = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += acc[i];
+  out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 }  // namespace gpc

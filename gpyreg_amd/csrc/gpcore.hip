@@ -57,10 +57,11 @@ struct gpc_ctx {
   int device = 0;
   hipStream_t st = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  static constexpr int MAXG = 4;
-  hipStream_t gst[MAXG] = {nullptr, nullptr, nullptr, nullptr};  // sample-group streams
-  hipEvent_t ev_up = nullptr, ev_done[MAXG] = {nullptr, nullptr, nullptr, nullptr};
+  static constexpr int MAXG = 8;
+  hipStream_t gst[MAXG] = {};  // sample-group streams
+  hipEvent_t ev_up = nullptr, ev_done[MAXG] = {}, ev_half[MAXG] = {};
   int groups = 2;
+  int stagger = 0;  // group g starts when group g-1 has factored its left half
   std::string err;
   std::string devinfo;
   // resident training data
@@ -247,7 +248,7 @@ struct Pipe {
 
   // Device kernels for `n` samples of the current chunk starting at chunk index `off`
   // (all per-sample buffers are indexed by chunk position), issued on stream `st`.
-  int device_section(hipStream_t st, int off, int n, hipEvent_t f0, hipEvent_t f1) {
+  int device_section(hipStream_t st, int off, int n, hipEvent_t f0, hipEvent_t f1, hipEvent_t half = nullptr) {
     Batch& b = *B;
     const int npad = b.npad, N = b.N, D = b.D;
     T* Ac = A + (size_t)off * sM;
@@ -283,6 +284,7 @@ struct Pipe {
     F.sA = F.sW = F.sT = sM;
     F.logdet = d_logdet;
     F.info = d_info;
+    F.half_event = half;
     // NLL only: the inverse of the whole matrix is not needed (only of left children)
     const bool full_inv = (mode != MODE_NLL);
     F.potrf_inv(0, npad, full_inv, mode == MODE_POST);
@@ -403,7 +405,9 @@ struct Pipe {
         const int lo = (int)((long long)cnt * g / groups), hi = (int)((long long)cnt * (g + 1) / groups);
         hipStream_t sg = c->gst[g];
         HIPCHK(c, hipStreamWaitEvent(sg, c->ev_up, 0));
-        int rc = device_section(sg, lo, hi - lo, g == 0 ? c->ev[1] : nullptr, nullptr);
+        if (c->stagger && g > 0) HIPCHK(c, hipStreamWaitEvent(sg, c->ev_half[g - 1], 0));
+        int rc = device_section(sg, lo, hi - lo, g == 0 ? c->ev[1] : nullptr, nullptr,
+                                c->stagger ? c->ev_half[g] : nullptr);
         if (rc) return rc;
         HIPCHK(c, hipEventRecord(c->ev_done[g], sg));
         HIPCHK(c, hipStreamWaitEvent(st, c->ev_done[g], 0));
@@ -899,7 +903,8 @@ int gpc_create(int device, gpc_ctx** out) {
   bool ok = hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming) == hipSuccess;
   for (int g = 0; g < gpc_ctx::MAXG && ok; ++g)
     ok = hipStreamCreateWithFlags(&c->gst[g], hipStreamNonBlocking) == hipSuccess &&
-         hipEventCreateWithFlags(&c->ev_done[g], hipEventDisableTiming) == hipSuccess;
+         hipEventCreateWithFlags(&c->ev_done[g], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&c->ev_half[g], hipEventDisableTiming) == hipSuccess;
   if (!ok) {
     g_create_err = "creating the sample-group streams failed";
     delete c;
@@ -908,6 +913,8 @@ int gpc_create(int device, gpc_ctx** out) {
   if (const char* e = getenv("GPC_GROUPS")) c->groups = std::max(1, std::min((int)gpc_ctx::MAXG, atoi(e)));
   if (const char* e = getenv("GPC_SMALL_BLOCKS")) gpc::g_small_launch_blocks = atoi(e);
   if (const char* e = getenv("GPC_GEMM_FLAGS")) gpc::g_gemm_flags = atoi(e);
+  if (const char* e = getenv("GPC_LEAF")) gpc::g_leaf_version = atoi(e);
+  if (const char* e = getenv("GPC_STAGGER")) c->stagger = atoi(e);
   *out = c;
   return 0;
 }
@@ -926,6 +933,7 @@ void gpc_destroy(gpc_ctx* c) {
   if (c->ev_up) (void)hipEventDestroy(c->ev_up);
   for (int g = 0; g < gpc_ctx::MAXG; ++g) {
     if (c->ev_done[g]) (void)hipEventDestroy(c->ev_done[g]);
+    if (c->ev_half[g]) (void)hipEventDestroy(c->ev_half[g]);
     if (c->gst[g]) (void)hipStreamDestroy(c->gst[g]);
   }
   if (c->st) (void)hipStreamDestroy(c->st);
@@ -1118,6 +1126,37 @@ int gpc_mfma_peak(gpc_ctx* c, int dtype, double* tflops, double* cycles_per_mfma
   HIPCHK(c, c->dbg2.ensure(64));
   long long* d_clk = c->dbg2.as<long long>();
   double best = 0, best_cyc = 0, best_ghz = 0;
+  if (dtype >= 2) {  // 2: f64 VALU FMA, 3: f32 VALU FMA (16 independent chains, 1 or 2 waves/SIMD)
+    for (int wps : {1, 2}) {
+      const int blocks = prop.multiProcessorCount * wps;
+      auto launch = [&]() {
+        if (dtype == 2)
+          hipLaunchKernelGGL((valu_peak_kernel<double>), dim3(blocks), dim3(256), 0, c->st, c->dbg1.as<double>(), iters, d_clk);
+        else
+          hipLaunchKernelGGL((valu_peak_kernel<float>), dim3(blocks), dim3(256), 0, c->st, c->dbg1.as<float>(), iters, d_clk);
+      };
+      launch();
+      HIPCHK(c, hipStreamSynchronize(c->st));
+      HIPCHK(c, hipEventRecord(c->ev[0], c->st));
+      for (int r = 0; r < 4; ++r) launch();
+      HIPCHK(c, hipEventRecord(c->ev[1], c->st));
+      HIPCHK(c, hipStreamSynchronize(c->st));
+      float ms = 0;
+      HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+      const double tf = 4.0 * blocks * 256.0 * iters * 16 * 2.0 / (ms * 1e-3) / 1e12;
+      long long hclk[2] = {0, 0};
+      HIPCHK(c, hipMemcpy(hclk, d_clk, sizeof hclk, hipMemcpyDeviceToHost));
+      if (tf > best) {
+        best = tf;
+        best_cyc = (double)hclk[0] / ((double)iters * 16) / wps;  // cycles per wave-instruction per SIMD
+        best_ghz = hclk[1] > 0 ? (double)hclk[0] / ((double)hclk[1] * 10.0) : 0.0;
+      }
+    }
+    *tflops = best;
+    if (cycles_per_mfma) *cycles_per_mfma = best_cyc;
+    if (clock_ghz) *clock_ghz = best_ghz;
+    return 0;
+  }
   // variants: accumulators per wave x waves per SIMD; the best one is the ceiling
   for (int nacc : {4, 16})
     for (int wps : {1, 2}) {

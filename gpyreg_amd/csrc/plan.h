@@ -32,6 +32,7 @@ struct Factor {
   long long sA, sW, sT;  // batch strides (elements)
   double* logdet;        // [batch], must be zeroed by the caller
   int* info;             // [batch], must be zeroed by the caller
+  hipEvent_t half_event = nullptr;  // recorded once the left half of the whole matrix is factored
   double flops = 0;      // algorithmic flops issued (tile-exact)
   int launches = 0;
   hipError_t err = hipSuccess;
@@ -65,8 +66,12 @@ struct Factor {
 
   void potrf_inv(int off, int n, bool need_inv, bool keep_L) {
     if (n == TILE) {
-      hipLaunchKernelGGL((leaf_kernel<T>), dim3(batch), dim3(256), 0, st, blk(A, off, off), sA, npad,
-                         blk(W, off, off), sW, npad, off, logdet, info);
+      if (g_leaf_version == 2)
+        hipLaunchKernelGGL((leaf2_kernel<T>), dim3(batch), dim3(256), 0, st, blk(A, off, off), sA, npad,
+                           blk(W, off, off), sW, npad, off, logdet, info);
+      else
+        hipLaunchKernelGGL((leaf_kernel<T>), dim3(batch), dim3(256), 0, st, blk(A, off, off), sA, npad,
+                           blk(W, off, off), sW, npad, off, logdet, info);
       flops += (2.0 / 3.0) * TILE * (double)TILE * TILE * batch;
       ++launches;
       return;
@@ -75,6 +80,7 @@ struct Factor {
     const int n1 = (q / 2) * TILE, n2 = n - n1;
     const int o1 = off, o2 = off + n1;
     potrf_inv(o1, n1, true, keep_L);
+    if (half_event && off == 0 && n == npad) (void)hipEventRecord(half_event, st);
     // 2. T21 = A21 * W11^T
     gemm(blk(Tm, o2, o1), sT, blk(A, o2, o1), sA, blk(W, o1, o1), sW, n2, n1, n1, false, false, 1.0,
          0, KLO_ZERO, KHI_COL, 0);

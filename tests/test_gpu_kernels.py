@@ -131,4 +131,7 @@ def test_mfma_peak_reports(ctx):
     t32, c32, g32 = ctx.mfma_peak(_lib.F32)
     print("MFMA ceiling fp64: %.1f TFLOP/s, %.1f cycles/MFMA/SIMD at %.2f GHz" % (t64, c64, g64))
     print("MFMA ceiling fp32: %.1f TFLOP/s, %.1f cycles/MFMA/SIMD at %.2f GHz" % (t32, c32, g32))
+    v64, vc64, _ = ctx.mfma_peak(2)
+    v32, vc32, _ = ctx.mfma_peak(3)
+    print("VALU FMA ceiling fp64: %.1f TFLOP/s, %.1f cycles/wave-instr/SIMD; fp32: %.1f TFLOP/s, %.1f cycles" % (v64, vc64, v32, vc32))
     assert t64 > 10 and t32 > 20
