@@ -16,14 +16,18 @@ fallback for the core: without the HIP library or a GPU these methods raise.
 
 from __future__ import annotations
 
+import math
+import threading
 from textwrap import indent
-from typing import Union
 
 import numpy as np
+import scipy.optimize
 from numpy.linalg import LinAlgError  # scipy.linalg.LinAlgError is this class
 
 from . import _lib
-from .covariance_functions import AbstractKernel
+from . import priors as _pr
+from .f_min_fill import f_min_fill
+from .slice_sample import SliceSampler
 
 
 class Posterior:
@@ -112,7 +116,8 @@ class GP:
         self.X = None
         self.y = None
         self.posteriors = None
-        self.no_prior = True
+        self.no_prior = None  # set_bounds must not touch the priors before set_priors ran
+        self.normalization_constants = None
         self.temporary_data = {}
         self.device = device
         if dtype not in _DTYPES:
@@ -126,6 +131,8 @@ class GP:
                 "kernels (SquaredExponential, Matern, RationalQuadraticARD and the isotropic "
                 "variants); user-defined Python kernels are not on the accelerated path."
             )
+        self.set_bounds()
+        self.set_priors()
 
     # ------------------------------------------------------------------ plumbing
     def _counts(self):
@@ -204,11 +211,359 @@ class GP:
         hyp = np.asarray(hyp, dtype=float)
         nlz, dnlz = self.nll_batch(hyp[None, :], compute_grad)
         nlZ = float(nlz[0])
-        if compute_prior and self.no_prior is not True:
-            raise NotImplementedError("hyperparameter priors are outside the accelerated path")
+        dnlZ = dnlz[0] if compute_grad else None
+        if compute_prior:
+            if compute_grad:
+                P, dP = self.__compute_log_priors(hyp, True)
+                nlZ -= P
+                dnlZ -= dP
+            else:
+                nlZ -= self.__compute_log_priors(hyp, False)
         if compute_grad:
-            return nlZ, dnlz[0]
+            return nlZ, dnlZ
         return nlZ
+
+    def __gp_obj_fun(self, hyp, compute_grad, swap_sign):
+        """Reference :1540-1559: nlZ minus log prior (when priors are set), optional sign swap."""
+        r = self.__compute_nlZ(hyp, compute_grad, self.no_prior is not True)
+        if compute_grad:
+            nlZ, dnlZ = r
+            return (-nlZ, -dnlZ) if swap_sign else (nlZ, dnlZ)
+        return -r if swap_sign else r
+
+    def _obj_batch(self, hyp, compute_grad=False):
+        """Batched ``__gp_obj_fun(hyp, compute_grad, False)`` over the rows of ``hyp``."""
+        hyp = np.atleast_2d(np.asarray(hyp, dtype=float))
+        nlz, dnlz = self.nll_batch(hyp, compute_grad)
+        nlz = nlz.copy()
+        if self.no_prior is not True:
+            for s in range(hyp.shape[0]):
+                if compute_grad:
+                    P, dP = self.__compute_log_priors(hyp[s], True)
+                    nlz[s] -= P
+                    dnlz[s] -= dP
+                else:
+                    nlz[s] -= self.__compute_log_priors(hyp[s], False)
+        return (nlz, dnlz) if compute_grad else nlz
+
+    # ------------------------------------------------------------------ bounds and priors
+    def _hyp_N(self):
+        return sum(self._counts())
+
+    def set_bounds(self, bounds: dict = None):
+        """Reference :147-210.  ``None`` entries (or ``bounds=None``) mean "not set" (NaN);
+        ``fit`` replaces those by the recommended bounds."""
+        lower = np.full((self._hyp_N(),), np.nan)
+        upper = np.full((self._hyp_N(),), np.nan)
+        i = 0
+        for name, cnt in self._hyper_info():
+            vals = None
+            if bounds is not None:
+                if name not in bounds:
+                    raise ValueError("Missing hyperparameter " + name)
+                vals = bounds[name]
+            if vals is not None:
+                lower[i:i + cnt], upper[i:i + cnt] = vals
+            i += cnt
+        self.lower_bounds, self.upper_bounds = lower, upper
+        if self.no_prior is not None:
+            self.__recompute_normalization_constants()
+
+    def bounds_to_dict(self, lower_bounds: np.ndarray, upper_bounds: np.ndarray):
+        """Reference :224-258."""
+        out, i = {}, 0
+        for name, cnt in self._hyper_info():
+            out[name] = (lower_bounds[i:i + cnt], upper_bounds[i:i + cnt])
+            i += cnt
+        return out
+
+    def get_bounds(self):
+        return self.bounds_to_dict(self.lower_bounds, self.upper_bounds)
+
+    def get_recommended_bounds(self, lower_bounds=None, upper_bounds=None):
+        """Reference :260-359: NaN entries are filled from the plugins' ``get_bounds_info``."""
+        if self.X is None or self.y is None:
+            raise ValueError("GP does not have X or y set!")
+
+        def resolve(v, current):
+            if isinstance(v, (list, tuple, np.ndarray)):
+                return np.array(v, dtype=float).copy()
+            if v == "current":
+                return current.copy()
+            if v is None or v == "recommended":
+                return np.full_like(current, np.nan)
+            raise ValueError("`lower_bounds` should be 'recommended'/`None`, 'current', or an array.")
+
+        lb = resolve(lower_bounds, self.lower_bounds)
+        ub = resolve(upper_bounds, self.upper_bounds)
+        info = [self.covariance.get_bounds_info(self.X, self.y),
+                self.noise.get_bounds_info(self.X, self.y),
+                self.mean.get_bounds_info(self.X, self.y)]
+        rec_lb = np.concatenate([d["LB"] for d in info])
+        rec_ub = np.concatenate([d["UB"] for d in info])
+        lb = np.where(np.isnan(lb), rec_lb, lb)
+        ub = np.where(np.isnan(ub), rec_ub, ub)
+        ub = np.maximum(lb, ub)
+        return self.bounds_to_dict(lb, ub)
+
+    def set_priors(self, priors: dict = None):
+        """Reference :418-514.  ``priors[name] = (type, params)`` with type one of
+        'gaussian' (mu, sigma), 'student_t' (mu, sigma, df), 'smoothbox' (a, b, sigma),
+        'smoothbox_student_t' (a, b, sigma, df); ``None`` = no prior."""
+        hp = _pr.empty_priors(self._hyp_N())
+        any_prior = False
+        i = 0
+        for name, cnt in self._hyper_info():
+            vals = None
+            if priors is not None:
+                if name not in priors:
+                    raise ValueError("Missing hyperparameter " + name)
+                vals = priors[name]
+            if vals is not None:
+                any_prior = True
+                kind, params = vals
+                sl = slice(i, i + cnt)
+                if kind == "gaussian":
+                    hp["mu"][sl], hp["sigma"][sl] = params
+                    hp["df"][sl] = 0
+                elif kind == "student_t":
+                    hp["mu"][sl], hp["sigma"][sl], hp["df"][sl] = params
+                elif kind == "smoothbox":
+                    hp["a"][sl], hp["b"][sl], hp["sigma"][sl] = params
+                    hp["df"][sl] = 0
+                elif kind == "smoothbox_student_t":
+                    hp["a"][sl], hp["b"][sl], hp["sigma"][sl], hp["df"][sl] = params
+                else:
+                    raise ValueError("Unknown hyperprior type " + kind)
+            i += cnt
+        self.hyper_priors = hp
+        self.no_prior = not any_prior
+        self.__recompute_normalization_constants()
+
+    def get_priors(self):
+        """Reference :361-416."""
+        hp = self.hyper_priors
+        out, i = {}, 0
+        for name, cnt in self._hyper_info():
+            sl = slice(i, i + cnt)
+            mu, sigma, df, a, b = (hp[k][sl] for k in ("mu", "sigma", "df", "a", "b"))
+            val = None
+            if np.all(np.isfinite(a)) and np.all(np.isfinite(b)) and np.all(np.isfinite(sigma)):
+                if np.all((df == 0) | (df == np.inf)):
+                    val = ("smoothbox", (a.copy(), b.copy(), sigma.copy()))
+                elif np.all(df > 0):
+                    val = ("smoothbox_student_t", (a.copy(), b.copy(), sigma.copy(), df.copy()))
+            elif np.all(np.isfinite(mu)) and np.all(np.isfinite(sigma)):
+                if np.all((df == 0) | (df == np.inf)):
+                    val = ("gaussian", (mu.copy(), sigma.copy()))
+                elif np.all(df > 0):
+                    val = ("student_t", (mu.copy(), sigma.copy(), df.copy()))
+            out[name] = val
+            i += cnt
+        return out
+
+    def __recompute_normalization_constants(self):
+        self.normalization_constants = _pr.normalization_constants(
+            self.hyper_priors, self.lower_bounds, self.upper_bounds)
+
+    def __compute_log_priors(self, hyp: np.ndarray, compute_grad: bool):
+        return _pr.log_priors(hyp, self.hyper_priors, self.lower_bounds, self.upper_bounds,
+                              self.normalization_constants, compute_grad)
+
+    # ------------------------------------------------------------------ fit
+    def fit(self, X=None, y=None, s2=None, hyp0=None, options: dict = None):
+        """Train the hyperparameters (reference :910-1232): space-filling design ->
+        multi-start L-BFGS-B -> slice sampling -> posteriors.
+
+        Same options and defaults as the reference.  What changes is how the core is
+        called: the design (``init_N`` = 1024 evaluations by default) is ONE device batch,
+        the ``opts_N`` optimisers advance in lock-step with their NLL+gradient requests
+        batched per iteration (each trajectory is unchanged: it only sees its own values),
+        the slice-sampling chain stays sequential, and the final posteriors are one batch.
+        """
+        options = options or {}
+        opts_N = options.get("opts_N", 3)
+        init_N = options.get("init_N", 2**10)
+        init_method = options.get("init_method", "sobol")
+        thin = options.get("thin", 5)
+        df_base = options.get("df_base", 7)
+        widths = options.get("widths", None)
+        tol_opt = options.get("tol_opt", 1e-5)
+        tol_opt_mcmc = options.get("tol_opt_mcmc", 1e-3)
+        sampler_name = options.get("sampler", "slicesample")
+        s_N = options.get("n_samples", 10)
+        burn_in = options.get("burn", thin * s_N)
+        lower_bounds = options.get("lower_bounds", "current")
+        upper_bounds = options.get("upper_bounds", "current")
+
+        X, y, s2 = self._convert_shapes(X, y, s2)
+        if X is not None:
+            self.X = X
+        if y is not None:
+            self.y = y
+        if s2 is not None:
+            self.s2 = s2
+        self._token = None
+        cov_N, noise_N, _ = self._counts()
+
+        info = [self.covariance.get_bounds_info(self.X, self.y),
+                self.noise.get_bounds_info(self.X, self.y),
+                self.mean.get_bounds_info(self.X, self.y)]
+        self.hyper_priors["df"][np.isnan(self.hyper_priors["df"])] = df_base
+
+        current = (isinstance(lower_bounds, str) and lower_bounds == "current"
+                   and isinstance(upper_bounds, str) and upper_bounds == "current")
+        if current and (np.any(np.isnan(self.lower_bounds)) or np.any(np.isnan(self.upper_bounds))):
+            self.set_bounds(self.get_recommended_bounds(self.lower_bounds, self.upper_bounds))
+        else:
+            self.set_bounds(self.get_recommended_bounds(lower_bounds, upper_bounds))
+        LB, UB = self.lower_bounds, self.upper_bounds
+        PLB = np.concatenate([d["PLB"] for d in info])
+        PUB = np.concatenate([d["PUB"] for d in info])
+        PLB = np.minimum(np.maximum(PLB, LB), UB)
+        PUB = np.maximum(np.minimum(PUB, UB), LB)
+
+        if hyp0 is None:
+            if self.posteriors is not None:
+                hyp0 = self.get_hyperparameters(as_array=True)
+            else:
+                hyp0 = np.reshape(np.minimum(np.maximum((PLB + PUB) / 2, LB), UB), (1, -1))
+        elif isinstance(hyp0, dict):
+            hyp0 = self.hyperparameters_from_dict(hyp0)
+        hyp0 = np.atleast_2d(hyp0)
+
+        tol = tol_opt_mcmc if (s_N > 0 and sampler_name != "laplace") else tol_opt
+
+        # 1. objective on the space-filling design: one batch (reference :1096-1130)
+        if init_N > 0:
+            X0, y0 = f_min_fill(lambda Xd: self._obj_batch(Xd, False), hyp0, LB, UB, PLB, PUB,
+                                self.hyper_priors, init_N, init_method)
+            hyp = X0[0:np.maximum(opts_N, 1), :]
+            if noise_N > 0 and 1 < opts_N < init_N:  # a good low-noise start for run #2
+                xx, noise_y = X0[opts_N:, :], y0[opts_N:]
+                order = np.argsort(xx[:, cov_N])
+                xx, noise_y = xx[order, :], noise_y[order]
+                idx_best = np.argmin(noise_y[0:math.ceil(0.2 * np.size(noise_y))])
+                hyp[1, :] = xx[idx_best, :]
+            widths_default = np.std(X0, axis=0, ddof=1) if init_N > 1 else np.zeros(shape=PLB.shape)
+        else:
+            nll = np.asarray(self._obj_batch(hyp0, False))
+            hyp = hyp0[np.argsort(nll), :]
+            widths_default = PUB - PLB
+
+        idx0 = widths_default == 0
+        if np.any(idx0):
+            if np.shape(hyp)[0] > 1:
+                widths_default[idx0] = np.std(hyp, axis=0, ddof=1)[idx0]
+                idx0 = widths_default == 0
+            if np.any(idx0):
+                widths_default[idx0] = np.minimum(1, UB[idx0] - LB[idx0])
+
+        eps_LB, eps_UB = np.reshape(LB.copy(), (1, -1)), np.reshape(UB.copy(), (1, -1))
+        LB_idx = (eps_LB != eps_UB) & np.isfinite(eps_LB)
+        UB_idx = (eps_LB != eps_UB) & np.isfinite(eps_UB)
+        eps_LB[LB_idx] = np.nextafter(eps_LB[LB_idx], np.inf)
+        eps_UB[UB_idx] = np.nextafter(eps_UB[UB_idx], -np.inf)
+        hyp = np.minimum(eps_UB, np.maximum(eps_LB, hyp))
+
+        # 2. multi-start L-BFGS-B, starts in lock-step (reference :1177-1187)
+        nll = np.full((np.maximum(opts_N, 1),), np.inf)
+        opts_N = int(np.minimum(opts_N, hyp.shape[0]))
+        opt_results = self._minimize_lockstep(hyp[:opts_N], LB, UB, tol)
+        for i, res in enumerate(opt_results):
+            hyp[i, :] = res.x
+            nll[i] = res.fun
+        if opts_N > 0:
+            optimize_result = opt_results[int(np.argmin(nll))]
+            hyp_start = hyp[int(np.argmin(nll)), :].copy()
+        else:
+            optimize_result = None
+            hyp_start = hyp[0, :].copy()
+
+        if s_N == 0:
+            hyp_start = np.reshape(hyp_start, (1, -1))
+            self.update(hyp=hyp_start)
+            return hyp_start, optimize_result, None
+
+        # 3. slice sampling from the best optimum: a sequential chain (reference :1205-1225)
+        if sampler_name != "slicesample":
+            raise ValueError("Unknown sampler!")
+        widths = widths_default if widths is None else np.minimum(widths, widths_default)
+        slicer = SliceSampler(lambda h: self.__gp_obj_fun(h, False, True), hyp_start, widths, LB, UB,
+                              {"display": "off", "diagnostics": False})
+        sampling_result = slicer.sample(s_N * thin, burn=burn_in)
+        hyp = sampling_result["samples"][thin - 1::thin, :]
+
+        # 4. posteriors for the retained samples: one batch (reference :1231)
+        self.update(hyp=hyp)
+        return hyp, optimize_result, sampling_result
+
+    def _minimize_lockstep(self, starts, LB, UB, tol):
+        """Run one ``scipy.optimize.minimize`` (L-BFGS-B) per start, each in its own thread;
+        their objective calls meet at a rendezvous that evaluates all pending requests as ONE
+        ``_obj_batch`` call.  Every optimiser sees exactly the values it would see alone."""
+        n = starts.shape[0]
+        if n == 0:
+            return []
+        bounds = list(zip(LB, UB))
+        if n == 1:
+            f = lambda h: self.__gp_obj_fun(h, True, False)
+            return [scipy.optimize.minimize(fun=f, x0=starts[0], jac=True, bounds=bounds, tol=tol)]
+
+        cv = threading.Condition()
+        state = {"active": n, "pending": {}, "results": {}, "error": None, "gen": 0}
+
+        def flush():  # caller holds cv
+            ids = sorted(state["pending"])
+            xs = np.stack([state["pending"][i] for i in ids])
+            state["pending"].clear()
+            try:
+                vals, grads = self._obj_batch(xs, True)
+                for k, i in enumerate(ids):
+                    state["results"][i] = (float(vals[k]), grads[k].copy())
+            except Exception as e:  # noqa: BLE001 - re-raised in every waiting optimiser
+                state["error"] = e
+            state["gen"] += 1
+            cv.notify_all()
+
+        def objective(i, x):
+            with cv:
+                if state["error"] is not None:
+                    raise state["error"]
+                state["pending"][i] = np.array(x, dtype=float)
+                if len(state["pending"]) == state["active"]:
+                    flush()
+                else:
+                    gen = state["gen"]
+                    while state["gen"] == gen:
+                        cv.wait()
+                if state["error"] is not None:
+                    raise state["error"]
+                return state["results"].pop(i)
+
+        out, errs = [None] * n, [None] * n
+
+        def worker(i):
+            try:
+                out[i] = scipy.optimize.minimize(fun=lambda x: objective(i, x), x0=starts[i], jac=True,
+                                                 bounds=bounds, tol=tol)
+            except Exception as e:  # noqa: BLE001
+                errs[i] = e
+            finally:
+                with cv:
+                    state["active"] -= 1
+                    if state["active"] > 0 and len(state["pending"]) == state["active"]:
+                        flush()
+
+        threads = [threading.Thread(target=worker, args=(i,)) for i in range(n)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for e in errs:
+            if e is not None:
+                raise e
+        return out
 
     def log_likelihood(self, hyp: object, compute_grad: bool = False):
         """(Positive) log marginal likelihood (reference :1468-1488).  With

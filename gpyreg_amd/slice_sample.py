@@ -1,0 +1,134 @@
+"""Bounded coordinate-wise slice sampler with adaptive widths.
+
+The sampler the reference uses to draw hyperparameter samples (gpyreg/slice_sample.py,
+a port of MATLAB ``slicesamplebnd``; Neal 2003, "shrinkage" procedure).  It is a strictly
+sequential Markov chain -- every evaluation depends on the previous one -- so it is NOT
+batched ("replicas only"); each ``log_f`` call is one device NLL evaluation.
+
+This implementation draws from the global NumPy RNG in the same order as the reference
+(one coordinate shuffle per sweep; per coordinate a slice level, an interval offset, then
+one uniform per shrinkage proposal), so that with the same seed and the same target values
+it walks the same chain.  Kept: bounds, optional stepping-out, width adaptation during
+burn-in (x1.2 when the first proposal is accepted, /1.1 after more than three shrinks, then
+5 x the burn-in standard deviation), thinning.  Dropped: Metropolis mixing, convergence
+diagnostics and the logging front-end, none of which ``GP.fit`` uses.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+
+class SliceSampler:
+    def __init__(self, log_f, x0, widths=None, LB=None, UB=None, options=None):
+        self.log_f = log_f
+        self.x0 = np.array(x0, dtype=float).copy()
+        if self.x0.ndim > 1:
+            raise ValueError("The initial point x0 needs to be a scalar or a 1D array")
+        D = self.x0.size
+        self.LB = np.full(D, -np.inf) if LB is None else np.array(LB, dtype=float).ravel() * np.ones(D)
+        self.UB = np.full(D, np.inf) if UB is None else np.array(UB, dtype=float).ravel() * np.ones(D)
+        if not np.all(self.UB >= self.LB):
+            raise ValueError("All upper bounds UB need to be equal or greater than lower bounds LB.")
+        if np.any(self.x0 < self.LB) or np.any(self.x0 > self.UB):
+            raise ValueError("The initial starting point X0 is outside the bounds.")
+        span = self.UB - self.LB
+        # the first interval may reach one ulp beyond the box (like the reference); the
+        # target is -inf there, so such proposals are simply shrunk away
+        self.LB_out = np.nextafter(self.LB, -np.inf)
+        self.UB_out = np.nextafter(self.UB, np.inf)
+        self.base_widths = None if widths is None else np.array(widths, dtype=float).ravel() * np.ones(D)
+        if self.base_widths is None:
+            w = span / 2
+            w[~np.isfinite(w)] = 10.0
+        else:
+            w = self.base_widths.copy()
+        w[self.LB == self.UB] = 1.0
+        if np.any(w <= 0) or np.any(~np.isfinite(w)):
+            raise ValueError("The widths vector needs to be all positive real numbers.")
+        self.widths = w
+        options = options or {}
+        self.step_out = options.get("step_out", False)
+        self.adaptive = options.get("adaptive", True)
+        self.func_count = 0
+
+    def _logp(self, x):
+        if np.any(x < self.LB) or np.any(x > self.UB):
+            return -np.inf, None
+        f = self.log_f(x)
+        self.func_count += 1
+        if np.any(np.isnan(f)):
+            return -np.inf, f
+        return float(np.sum(f)), f
+
+    def sample(self, N: int, thin: int = 1, burn: int = None):
+        xx = self.x0
+        D = xx.size
+        if burn is None:
+            burn = 0 if self.func_count > 0 else round(N / 3)
+        if not np.isscalar(thin) or thin <= 0:
+            raise ValueError("The thinning factor option needs to be a positive integer.")
+        if not np.isscalar(burn) or burn < 0:
+            raise ValueError("The burn-in samples option needs to be a non-negative integer.")
+        total = N + (N - 1) * (thin - 1)
+        samples = np.zeros((N, D))
+        f_vals = np.zeros((N, 1))
+        sum1, sum2 = np.zeros(D), np.zeros(D)
+        log_Px, f_val = self._logp(xx)
+        if not np.isfinite(log_Px):
+            raise ValueError("The initial starting point X0 needs to evaluate to a real number (not Inf or NaN).")
+        perm = np.arange(D)
+        for it in range(total + burn):
+            x_l, x_r, xprime = xx.copy(), xx.copy(), xx.copy()
+            np.random.shuffle(perm)
+            for dd in perm:
+                if self.LB[dd] == self.UB[dd]:
+                    continue
+                log_u = log_Px + np.log(np.random.rand())  # slice level
+                rr = np.random.rand()  # position of the current point inside the first interval
+                x_l[dd] = np.fmax(x_l[dd] - rr * self.widths[dd], self.LB_out[dd])
+                x_r[dd] = np.fmin(x_r[dd] + (1 - rr) * self.widths[dd], self.UB_out[dd])
+                if self.step_out:
+                    while self._logp(x_l)[0] > log_u:
+                        x_l[dd] -= self.widths[dd]
+                    while self._logp(x_r)[0] > log_u:
+                        x_r[dd] += self.widths[dd]
+                shrink = 0
+                while True:
+                    shrink += 1
+                    xprime[dd] = np.random.rand() * (x_r[dd] - x_l[dd]) + x_l[dd]
+                    log_Px, f_val = self._logp(xprime)
+                    if log_Px > log_u:
+                        break
+                    if xprime[dd] > xx[dd]:
+                        x_r[dd] = xprime[dd]
+                    elif xprime[dd] < xx[dd]:
+                        x_l[dd] = xprime[dd]
+                    else:
+                        break  # shrunk onto the current point
+                if it < burn and self.adaptive:
+                    delta = self.UB[dd] - self.LB[dd]
+                    if shrink > 3:
+                        floor = np.abs(np.spacing(delta)) if np.isfinite(delta) else np.spacing(1)
+                        self.widths[dd] = np.maximum(self.widths[dd] / 1.1, floor)
+                    elif shrink < 2:
+                        self.widths[dd] = np.minimum(self.widths[dd] * 1.2, delta)
+                xx[dd] = xprime[dd]
+                x_l[dd] = x_r[dd] = xx[dd]
+            if it >= burn and (it - burn) % thin == 0:
+                k = (it - burn) // thin
+                samples[k] = xx
+                f_vals[k] = f_val
+            if burn / 2 <= it < burn:
+                sum1 += xx
+                sum2 += xx**2
+                if it == burn - 1 and self.adaptive:
+                    n = np.floor(burn / 2)
+                    new_w = np.fmin(5 * np.sqrt(np.maximum(sum2 / n - (sum1 / n) ** 2, 0)),
+                                    self.UB_out - self.LB_out)
+                    if self.base_widths is None:
+                        self.widths = new_w
+                    else:
+                        self.widths = np.maximum(new_w, np.sqrt(new_w * self.base_widths))
+        return {"samples": samples, "f_vals": f_vals, "exit_flag": 0, "log_priors": np.zeros(N),
+                "R": None, "eff_N": None}

@@ -11,6 +11,8 @@ script reproduces the files bit-for-bit on the same numpy/scipy/OpenBLAS.
 Files written next to this script:
   cov_cases.npz    covariance.compute(): K, dK, K(X,X*), diag for every kernel
   core_cases.npz   GP.__compute_nlZ (nlZ, dnlZ), Posterior fields, GP.predict
+  prior_cases.npz  GP.__compute_log_priors, normalization constants, f_min_fill designs
+  fit_cases.npz    GP.fit end to end under a fixed global seed (hyp samples, predictions)
 """
 
 import os
@@ -227,7 +229,111 @@ def core_cases():
     print("core cases:", len(names))
 
 
+def prior_cases():
+    """GP.__compute_log_priors / normalization constants / f_min_fill design from the reference."""
+    from gpyreg.f_min_fill import f_min_fill
+
+    out = {}
+    names = []
+    kinds = ["gaussian", "student_t", "smoothbox", "smoothbox_student_t", None]
+    for idx in range(12):
+        rng = np.random.default_rng(12000 + idx)
+        D = 1 + idx % 3
+        cov = [KERNELS["se"], KERNELS["rq"], KERNELS["matern_iso5"]][idx % 3]()
+        mean = [MEANS["const"], MEANS["negquad"], MEANS["zero"]][(idx // 3) % 3]()
+        noise = make_noise([(1, 0, 0), (1, 2, 0), (1, 0, 1)][idx % 3])
+        gp = gpr.GP(D=D, covariance=cov, mean=mean, noise=noise)
+        info = (cov.hyperparameter_info(D) + noise.hyperparameter_info() + mean.hyperparameter_info(D))
+        hyp_N = sum(c for _, c in info)
+        pri, bnd = {}, {}
+        for k, (name, cnt) in enumerate(info):
+            kind = kinds[(idx + k) % 5]
+            if kind == "gaussian":
+                pri[name] = (kind, (rng.standard_normal(), np.exp(0.3 * rng.standard_normal())))
+            elif kind == "student_t":
+                pri[name] = (kind, (rng.standard_normal(), np.exp(0.3 * rng.standard_normal()), 3 + 4 * rng.uniform()))
+            elif kind == "smoothbox":
+                pri[name] = (kind, (-1.0 - rng.uniform(), 1.0 + rng.uniform(), 0.5 + rng.uniform()))
+            elif kind == "smoothbox_student_t":
+                pri[name] = (kind, (-1.0 - rng.uniform(), 1.0 + rng.uniform(), 0.5 + rng.uniform(), 3 + 4 * rng.uniform()))
+            else:
+                pri[name] = None
+            if (idx + k) % 4 == 0:
+                bnd[name] = None
+            elif (idx + k) % 7 == 3:
+                bnd[name] = (np.full(cnt, 0.25), np.full(cnt, 0.25))  # fixed dimension
+            else:
+                bnd[name] = (np.full(cnt, -4.0 - rng.uniform()), np.full(cnt, 4.0 + rng.uniform()))
+        gp.set_priors(pri)
+        gp.set_bounds(bnd)
+        gp.hyper_priors["df"][np.isnan(gp.hyper_priors["df"])] = 7  # what fit() does (:1029)
+        gp._GP__recompute_normalization_constants()
+        tag = f"p{idx:03d}"
+        H = 3.0 * rng.standard_normal((6, hyp_N))
+        H[:, gp.lower_bounds == gp.upper_bounds] = 0.25
+        H[5, :] = np.where(np.isnan(gp.lower_bounds), H[5], 0.25)
+        lp = np.zeros(6)
+        dlp = np.zeros((6, hyp_N))
+        for r in range(6):
+            lp[r], dlp[r] = gp._GP__compute_log_priors(H[r], True)
+        for k in ("mu", "sigma", "df", "a", "b"):
+            out[tag + "_" + k] = gp.hyper_priors[k]
+        out[tag + "_lb"], out[tag + "_ub"] = gp.lower_bounds, gp.upper_bounds
+        out[tag + "_norm"] = gp.normalization_constants
+        out[tag + "_H"], out[tag + "_lp"], out[tag + "_dlp"] = H, lp, dlp
+        # design: reference f_min_fill with an analytic objective under a fixed global seed
+        LB = np.where(np.isnan(gp.lower_bounds), -5.0, gp.lower_bounds)
+        UB = np.where(np.isnan(gp.upper_bounds), 5.0, gp.upper_bounds)
+        PLB, PUB = np.maximum(LB, -2.0), np.minimum(UB, 2.0)
+        PLB, PUB = np.minimum(PLB, PUB), np.maximum(PLB, PUB)
+        x0 = np.clip(0.5 * rng.standard_normal((2, hyp_N)), LB, UB)
+        np.random.seed(4321 + idx)
+        fobj = lambda h: float(np.sum((h - 0.3) ** 2) + np.sin(3 * h[0]))
+        Xd, yd = f_min_fill(fobj, x0, LB, UB, PLB, PUB, gp.hyper_priors, 40, "sobol")
+        out[tag + "_dLB"], out[tag + "_dUB"], out[tag + "_dPLB"], out[tag + "_dPUB"] = LB, UB, PLB, PUB
+        out[tag + "_dx0"], out[tag + "_dX"], out[tag + "_dy"] = x0, Xd, yd
+        names.append(f"{tag}|{hyp_N}")
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "prior_cases.npz"), **out)
+    print("prior cases:", len(names))
+
+
+def fit_cases():
+    """GP.fit end to end (examples/example_2.py shape: seeded data, priors, design, L-BFGS-B
+    multi-start, slice sampling, update, predict) from the reference."""
+    out = {}
+    for idx, (kname, N, D) in enumerate([("se", 20, 2), ("matern5", 40, 1)]):
+        np.random.seed(1235 + idx)
+        X = np.random.uniform(low=-3, high=3, size=(N, D))
+        y = np.reshape(np.sin(np.sum(X, 1)) + np.random.normal(scale=0.1, size=N), (-1, 1))
+        gp = gpr.GP(D=D, covariance=KERNELS[kname](), mean=MEANS["const"](), noise=make_noise((1, 0, 0)))
+        gp.set_priors({
+            "covariance_log_outputscale": ("student_t", (0, np.log(10), 3)),
+            "covariance_log_lengthscale": ("gaussian", (np.log(np.std(X, ddof=1)), np.log(10))),
+            "noise_log_scale": ("gaussian", (np.log(1e-3), 1.0)),
+            "mean_const": ("smoothbox", (np.min(y), np.max(y), 1.0)),
+        })
+        opts = {"n_samples": 6, "init_N": 128, "thin": 2, "burn": 12, "opts_N": 3}
+        hyp, opt_res, samp = gp.fit(X=X, y=y, options=opts)
+        xs = np.random.uniform(-3, 3, size=(15, D))
+        mu, s2 = gp.predict(xs, add_noise=False)
+        tag = f"f{idx}"
+        out[tag + "_X"], out[tag + "_y"], out[tag + "_hyp"] = X, y, hyp
+        out[tag + "_opt_x"], out[tag + "_opt_fun"] = opt_res.x, np.array(opt_res.fun)
+        out[tag + "_xs"], out[tag + "_mu"], out[tag + "_s2"] = xs, mu, s2
+        out[tag + "_lb"], out[tag + "_ub"] = gp.lower_bounds, gp.upper_bounds
+        print(tag, kname, "opt fun", opt_res.fun, "hyp[0]", hyp[0])
+    np.savez_compressed(os.path.join(HERE, "fit_cases.npz"), **out)
+
+
 if __name__ == "__main__":
-    cov_cases()
-    core_cases()
+    which = sys.argv[1:] or ["cov", "core", "prior", "fit"]
+    if "cov" in which:
+        cov_cases()
+    if "core" in which:
+        core_cases()
+    if "prior" in which:
+        prior_cases()
+    if "fit" in which:
+        fit_cases()
     sys.exit(0)
