@@ -48,6 +48,8 @@ SIGNATURES = {
     "gpc_post_fetch": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
     "gpc_post_free": (C.c_int, [_vp]),
     "gpc_predict": (C.c_int, [_vp, _dp, C.c_int, _dp, _dp]),
+    "gpc_predict_full": (C.c_int, [_vp, _dp, C.c_int, _dp, _dp]),
+    "gpc_quad": (C.c_int, [_vp, _dp, _dp, C.c_int, C.c_int, _dp, _dp]),
     "gpc_last_timing": (C.c_int, [_vp, _dp, _dp]),
     "gpc_mfma_peak": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
     "gpc_debug_gemm": (
@@ -258,6 +260,24 @@ class PostHandle:
         rc = self.ctx._lib.gpc_predict(self._h, _ptr(xs), M, _ptr(fmu), _ptr(fs2))
         self.ctx._check(rc, "gpc_predict")
         return fmu, fs2
+
+    def predict_full(self, x_star):
+        xs = _f64(x_star)
+        M = xs.shape[0]
+        fmu = np.empty((M, self.S))
+        cov = np.empty((self.S, M, M))
+        rc = self.ctx._lib.gpc_predict_full(self._h, _ptr(xs), M, _ptr(fmu), _ptr(cov))
+        self.ctx._check(rc, "gpc_predict_full")
+        return fmu, cov
+
+    def quad(self, mu, sigma, compute_var):
+        mu, sigma = _f64(mu), _f64(sigma)
+        M = mu.shape[0]
+        za = np.empty((M, self.S))
+        zkz = np.empty((M, self.S)) if compute_var else None
+        rc = self.ctx._lib.gpc_quad(self._h, _ptr(mu), _ptr(sigma), M, 1 if compute_var else 0, _ptr(za), _ptr(zkz))
+        self.ctx._check(rc, "gpc_quad")
+        return za, zkz
 
     def free(self):
         if self._h:

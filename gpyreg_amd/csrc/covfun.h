@@ -339,6 +339,39 @@ __global__ void cross_kernel(CovDesc cd, const double* __restrict__ Xs_all,
 }
 
 // ---------------------------------------------------------------------------------
+// Bayesian-quadrature kernel means (gaussian_process.py:1908-1921), SE kernel only:
+//   z[b][n][j] = exp( ln sf2 + sum ln ell - sum_l ln tau_jl - 1/2 sum_l ((mu_jl - X_nl)/tau_jl)^2 )
+//   tau_jl = sqrt(sigma_jl^2 + ell_l^2),  ell_l = dv[b][l] (the SE scaling divides X by ell)
+// laid out like a cross covariance (npad x mpad, zero padding).
+// grid = (mpad/64, npad/4, batch), block = (64, 4)
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ void quad_z_kernel(const double* __restrict__ X, const double* __restrict__ mu,
+                              const double* __restrict__ sigma, const double* __restrict__ mul_all,
+                              const double* __restrict__ dv_all, const double* __restrict__ sp_all, int n,
+                              int npad, int m, int mpad, int D, T* __restrict__ Z_all, long long sZ) {
+  const int b = blockIdx.z;
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  const int i = blockIdx.y * 4 + threadIdx.y;
+  if (i >= npad || j >= mpad) return;
+  double v = 0.0;
+  if (i < n && j < m) {
+    const double* ell = dv_all + (size_t)b * D;
+    const double sf2 = sp_all[(size_t)b * SP_STRIDE + SP_SF2];
+    double lnnf = log(sf2), acc = 0.0;
+    for (int l = 0; l < D; ++l) {
+      const double sg = sigma[(size_t)j * D + l];
+      const double tau = sqrt(sg * sg + ell[l] * ell[l]);
+      lnnf += log(ell[l]) - log(tau);
+      const double d = (mu[(size_t)j * D + l] - X[(size_t)i * D + l]) / tau;
+      acc += d * d;
+    }
+    v = exp(lnnf - 0.5 * acc);
+  }
+  Z_all[(size_t)b * sZ + (size_t)i * mpad + j] = (T)v;
+}
+
+// ---------------------------------------------------------------------------------
 // Standalone compute(): K (n x m) and optionally dK (n x n x cov_N) in double.
 // Xa: scaled rows (n x D); Xb: scaled cols (m x D).  grid = (ceil(m/64), ceil(n/4))
 // ---------------------------------------------------------------------------------

@@ -75,7 +75,7 @@ struct gpc_ctx {
   DevBuf scal;                   // logdet | quad | (ints) info
   DevBuf parts, gout, diagq;     // trace pass
   DevBuf dmb, dsn2b, mg, ng;     // mean / noise gradient inputs and outputs
-  DevBuf ks, vb, xss, pout;      // predict
+  DevBuf ks, vb, kss, xss, pout; // predict / predict_full / quad
   DevBuf dbg1, dbg2, dbg3;       // debug hooks / fetch staging
   double ms_total = 0, ms_factor = 0;
   double last_flops = 0;
@@ -635,28 +635,40 @@ int post_impl(gpc_ctx* c, Batch& b, gpc_post* po, double* sn2_mult, int* L_chol,
   return 0;
 }
 
+// Shared by predict / predict_full / quad: for every posterior sample s build a right-hand
+// side matrix R_s (npad x mpad: cross covariances, or quadrature kernel means), then
+//   lin[j*S+s]  = R_s[:, j] . alpha_s
+//   quad[j*S+s] = |W_s R_s[:, j]|^2          (L_chol;  the caller divides by sl)
+//               = R_s[:, j] . (L_s R_s[:, j]) (low noise, L = -inv)
+//   full[s]     = Kss_s - (W R)^T (W R) / sl   or   Kss_s + R^T (L R)     (mode_full)
+// mode: 0 = cross covariance of xa (M x D) with the training inputs; 1 = quadrature
+// vectors z for Gaussian measures N(xa[j], diag(xb[j]^2)) (gaussian_process.py:1908-1921).
 template <typename T>
-int predict_impl(gpc_post* po, const double* xstar, int M, double* fmu, double* fs2) {
+int rhs_products(gpc_post* po, int mode, const double* xa, const double* xb, int M, bool want_quad,
+                 double* lin, double* quad, double* full) {
   gpc_ctx* c = po->ctx;
   const int S = po->S, N = po->N, D = po->D, npad = po->npad;
   const int mpad = pad_tile(M);
   hipStream_t st = c->st;
   const long long sM = (long long)npad * npad;
   const long long sKs = (long long)npad * mpad;
-  // chunk over samples so that Ks and V fit comfortably
-  const size_t per = 2ull * npad * mpad * sizeof(T);
-  size_t budget = (size_t)((free_device_bytes() + c->ks.bytes + c->vb.bytes) * 0.8);
+  const long long sKss = (long long)mpad * mpad;
+  const size_t per = (2ull * npad * mpad + (full ? (size_t)mpad * mpad : 0)) * sizeof(T);
+  size_t budget = (size_t)((free_device_bytes() + c->ks.bytes + c->vb.bytes + c->kss.bytes) * 0.8);
   int chunk = (int)std::max<size_t>(1, std::min<size_t>(S, budget / per));
   HIPCHK(c, c->ks.ensure((size_t)chunk * sKs * sizeof(T)));
   HIPCHK(c, c->vb.ensure((size_t)chunk * sKs * sizeof(T)));
-  HIPCHK(c, c->xss.ensure(((size_t)chunk * mpad * D + (size_t)M * D) * 8));
+  if (full) HIPCHK(c, c->kss.ensure((size_t)chunk * sKss * sizeof(T)));
+  HIPCHK(c, c->xss.ensure(((size_t)chunk * mpad * D + 2 * (size_t)M * D) * 8));
   HIPCHK(c, c->xs.ensure((size_t)chunk * npad * D * 8));
   HIPCHK(c, c->spb.ensure((size_t)chunk * SP_STRIDE * 8));
   HIPCHK(c, c->mulb.ensure((size_t)chunk * D * 8));
   HIPCHK(c, c->divb.ensure((size_t)chunk * D * 8));
   HIPCHK(c, c->pout.ensure((size_t)chunk * mpad * 2 * 8));
-  double* d_xraw = c->xss.as<double>() + (size_t)chunk * mpad * D;
-  HIPCHK(c, hipMemcpyAsync(d_xraw, xstar, (size_t)M * D * 8, hipMemcpyHostToDevice, st));
+  double* d_xa = c->xss.as<double>() + (size_t)chunk * mpad * D;
+  double* d_xb = d_xa + (size_t)M * D;
+  HIPCHK(c, hipMemcpyAsync(d_xa, xa, (size_t)M * D * 8, hipMemcpyHostToDevice, st));
+  if (xb) HIPCHK(c, hipMemcpyAsync(d_xb, xb, (size_t)M * D * 8, hipMemcpyHostToDevice, st));
   std::vector<double> hmu((size_t)chunk * mpad), hv((size_t)chunk * mpad);
 
   for (int s0 = 0; s0 < S; s0 += chunk) {
@@ -665,21 +677,28 @@ int predict_impl(gpc_post* po, const double* xstar, int M, double* fmu, double* 
                              hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->mulb.p, &po->mul[(size_t)s0 * D], (size_t)cnt * D * 8, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->divb.p, &po->dv[(size_t)s0 * D], (size_t)cnt * D * 8, hipMemcpyHostToDevice, st));
-    {
+    T* Ks = c->ks.as<T>();
+    T* V = c->vb.as<T>();
+    if (mode == 0) {
       long long tot = (long long)npad * D;
       hipLaunchKernelGGL(scale_x_kernel, dim3((unsigned)((tot + 255) / 256), cnt), dim3(256), 0, st,
                          c->dX.as<double>(), N, npad, D, c->mulb.as<double>(), c->divb.as<double>(),
                          c->xs.as<double>());
       tot = (long long)mpad * D;
       hipLaunchKernelGGL(scale_x_kernel, dim3((unsigned)((tot + 255) / 256), cnt), dim3(256), 0, st,
-                         (const double*)d_xraw, M, mpad, D, c->mulb.as<double>(), c->divb.as<double>(),
+                         (const double*)d_xa, M, mpad, D, c->mulb.as<double>(), c->divb.as<double>(),
                          c->xss.as<double>());
+      hipLaunchKernelGGL((cross_kernel<T>), dim3(mpad / 64, npad / 4, cnt), dim3(64, 4), 0, st, po->cd,
+                         c->xs.as<double>(), c->xss.as<double>(), c->spb.as<double>(), N, npad, M, mpad, Ks, sKs);
+      if (full)
+        hipLaunchKernelGGL((cross_kernel<T>), dim3(mpad / 64, mpad / 4, cnt), dim3(64, 4), 0, st, po->cd,
+                           c->xss.as<double>(), c->xss.as<double>(), c->spb.as<double>(), M, mpad, M, mpad,
+                           c->kss.as<T>(), sKss);
+    } else {
+      hipLaunchKernelGGL((quad_z_kernel<T>), dim3(mpad / 64, npad / 4, cnt), dim3(64, 4), 0, st,
+                         c->dX.as<double>(), (const double*)d_xa, (const double*)d_xb, c->mulb.as<double>(),
+                         c->divb.as<double>(), c->spb.as<double>(), N, npad, M, mpad, D, Ks, sKs);
     }
-    T* Ks = c->ks.as<T>();
-    T* V = c->vb.as<T>();
-    hipLaunchKernelGGL((cross_kernel<T>), dim3(mpad / 64, npad / 4, cnt), dim3(64, 4), 0, st, po->cd,
-                       c->xs.as<double>(), c->xss.as<double>(), c->spb.as<double>(), N, npad, M, mpad, Ks, sKs);
-    // fmu = Ks^T alpha
     double* d_mu = c->pout.as<double>();
     double* d_v = d_mu + (size_t)chunk * mpad;
     hipLaunchKernelGGL((colsum_vec_kernel<T>), dim3(mpad / 64, cnt), dim3(256), 0, st, (const T*)Ks, sKs, mpad,
@@ -687,10 +706,11 @@ int predict_impl(gpc_post* po, const double* xstar, int M, double* fmu, double* 
     HIPCHK(c, hipGetLastError());
     // runs of equal L_chol share launches
     int a = 0;
-    while (a < cnt) {
+    while ((want_quad || full) && a < cnt) {
       int e = a;
       while (e < cnt && po->lchol[s0 + e] == po->lchol[s0 + a]) ++e;
       const int len = e - a;
+      const bool lch = po->lchol[s0 + a] != 0;
       GemmArgs g;
       g.B = Ks + (size_t)a * sKs;
       g.C = V + (size_t)a * sKs;
@@ -705,39 +725,72 @@ int predict_impl(gpc_post* po, const double* xstar, int M, double* fmu, double* 
       g.beta = 0;
       g.klo = KLO_ZERO;
       g.lower_only = 0;
-      g.tiles_n = mpad / TILE;
-      if (po->lchol[s0 + a]) {
-        g.A = po->W.as<T>() + (size_t)(s0 + a) * sM;  // V = W Ks  (k <= row tile)
-        g.khi = KHI_ROW;
-        HIPCHK(c, launch_gemm<T>(st, g, false, true, len));
-        hipLaunchKernelGGL((colsum_prod_kernel<T>), dim3(mpad / 64, len), dim3(256), 0, st,
-                           (const T*)(V + (size_t)a * sKs), sKs, (const T*)(V + (size_t)a * sKs), sKs, mpad,
-                           npad, mpad, d_v + (size_t)a * mpad);
-      } else {
-        g.A = po->A.as<T>() + (size_t)(s0 + a) * sM;  // G = L Ks with L = -inv (full symmetric)
-        g.khi = KHI_FULL;
-        HIPCHK(c, launch_gemm<T>(st, g, false, true, len));
-        hipLaunchKernelGGL((colsum_prod_kernel<T>), dim3(mpad / 64, len), dim3(256), 0, st,
-                           (const T*)(Ks + (size_t)a * sKs), sKs, (const T*)(V + (size_t)a * sKs), sKs, mpad,
-                           npad, mpad, d_v + (size_t)a * mpad);
+      g.A = (lch ? po->W.as<T>() : po->A.as<T>()) + (size_t)(s0 + a) * sM;  // V = W R | G = L R
+      g.khi = lch ? KHI_ROW : KHI_FULL;
+      HIPCHK(c, launch_gemm<T>(st, g, false, true, len));
+      const T* left = lch ? (const T*)(V + (size_t)a * sKs) : (const T*)(Ks + (size_t)a * sKs);
+      hipLaunchKernelGGL((colsum_prod_kernel<T>), dim3(mpad / 64, len), dim3(256), 0, st, left, sKs,
+                         (const T*)(V + (size_t)a * sKs), sKs, mpad, npad, mpad, d_v + (size_t)a * mpad);
+      if (full) {
+        // Kss -= V^T V / sl  (per sample: alpha differs)   |   Kss += R^T G
+        for (int i = a; i < e; ++i) {
+          GemmArgs f;
+          f.A = lch ? (const void*)(V + (size_t)i * sKs) : (const void*)(Ks + (size_t)i * sKs);
+          f.B = V + (size_t)i * sKs;
+          f.C = c->kss.as<T>() + (size_t)i * sKss;
+          f.sA = f.sB = f.sC = 0;
+          f.lda = f.ldb = f.ldc = mpad;
+          f.M = f.N = mpad;
+          f.K = npad;
+          f.alpha = lch ? -1.0 / po->sp[(size_t)(s0 + i) * SP_STRIDE + SP_SL] : 1.0;
+          f.beta = 1;
+          f.klo = KLO_ZERO;
+          f.khi = KHI_FULL;
+          f.lower_only = 0;
+          HIPCHK(c, launch_gemm<T>(st, f, true, true, 1));
+        }
       }
       a = e;
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(hmu.data(), d_mu, (size_t)cnt * mpad * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(hv.data(), d_v, (size_t)cnt * mpad * 8, hipMemcpyDeviceToHost, st));
+    if (want_quad) HIPCHK(c, hipMemcpyAsync(hv.data(), d_v, (size_t)cnt * mpad * 8, hipMemcpyDeviceToHost, st));
+    if (full) {
+      HIPCHK(c, c->dbg3.ensure((size_t)M * M * 8));
+      for (int i = 0; i < cnt; ++i) {
+        dim3 gn((M + 63) / 64, (M + 3) / 4), blk(64, 4);
+        hipLaunchKernelGGL((extract_kernel<T>), gn, blk, 0, st, (const T*)(c->kss.as<T>() + (size_t)i * sKss),
+                           mpad, M, 2, c->dbg3.as<double>());
+        HIPCHK(c, hipMemcpyAsync(full + (size_t)(s0 + i) * M * M, c->dbg3.p, (size_t)M * M * 8,
+                                 hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+      }
+    }
     HIPCHK(c, hipStreamSynchronize(st));
     for (int i = 0; i < cnt; ++i) {
       const int s = s0 + i;
-      const double sf2 = po->sp[(size_t)s * SP_STRIDE + SP_SF2];
-      const double sl = po->sp[(size_t)s * SP_STRIDE + SP_SL];
       for (int j = 0; j < M; ++j) {
-        fmu[(size_t)j * S + s] = hmu[(size_t)i * mpad + j];
-        const double q = hv[(size_t)i * mpad + j];
-        // L_chol: kss - sum(V*V), V = sW * (W Ks), sW^2 = 1/sl   (:1752-1760)
-        // else  : kss + sum(Ks * (L Ks))                          (:1762-1764)
-        fs2[(size_t)j * S + s] = po->lchol[s] ? sf2 - q / sl : sf2 + q;
+        lin[(size_t)j * S + s] = hmu[(size_t)i * mpad + j];
+        if (want_quad) quad[(size_t)j * S + s] = hv[(size_t)i * mpad + j];
       }
+    }
+  }
+  return 0;
+}
+
+template <typename T>
+int predict_impl(gpc_post* po, const double* xstar, int M, double* fmu, double* fs2) {
+  int rc = rhs_products<T>(po, 0, xstar, nullptr, M, true, fmu, fs2, nullptr);
+  if (rc) return rc;
+  const int S = po->S;
+  for (int s = 0; s < S; ++s) {
+    const double sf2 = po->sp[(size_t)s * SP_STRIDE + SP_SF2];
+    const double sl = po->sp[(size_t)s * SP_STRIDE + SP_SL];
+    for (int j = 0; j < M; ++j) {
+      const double q = fs2[(size_t)j * S + s];
+      // L_chol: kss - sum(V*V), V = sW * (W Ks), sW^2 = 1/sl   (:1752-1760)
+      // else  : kss + sum(Ks * (L Ks))                          (:1762-1764)
+      fs2[(size_t)j * S + s] = po->lchol[s] ? sf2 - q / sl : sf2 + q;
     }
   }
   return 0;
@@ -925,7 +978,7 @@ void gpc_destroy(gpc_ctx* c) {
   (void)hipStreamSynchronize(c->st);
   DevBuf* bufs[] = {&c->dX,   &c->mA,    &c->mW,  &c->mT,   &c->xs,   &c->spb,  &c->mulb, &c->divb,
                     &c->dvec, &c->rvec,  &c->zvec, &c->avec, &c->scal, &c->parts, &c->gout, &c->diagq,
-                    &c->dmb,  &c->dsn2b, &c->mg,  &c->ng,   &c->ks,   &c->vb,   &c->xss,  &c->pout,
+                    &c->dmb,  &c->dsn2b, &c->mg,  &c->ng,   &c->ks,   &c->vb,   &c->xss,  &c->pout, &c->kss,
                     &c->dbg1, &c->dbg2,  &c->dbg3};
   for (DevBuf* b : bufs) b->release();
   for (auto& ev : c->ev)
@@ -1107,6 +1160,40 @@ int gpc_predict(gpc_post* po, const double* xstar, int M, double* fmu, double* f
   HIPCHK(c, hipSetDevice(c->device));
   return po->dtype == GPC_F64 ? predict_impl<double>(po, xstar, M, fmu, fs2)
                               : predict_impl<float>(po, xstar, M, fmu, fs2);
+}
+
+int gpc_predict_full(gpc_post* po, const double* xstar, int M, double* fmu, double* cov) {
+  if (!po) return -2;
+  gpc_ctx* c = po->ctx;
+  if (!xstar || !fmu || !cov || M <= 0) FAIL(c, "gpc_predict_full: bad arguments");
+  for (int s = 0; s < po->S; ++s)
+    if (po->info[s] != 0) FAIL(c, "gpc_predict_full: posterior contains a failed factorization");
+  HIPCHK(c, hipSetDevice(c->device));
+  return po->dtype == GPC_F64 ? rhs_products<double>(po, 0, xstar, nullptr, M, false, fmu, nullptr, cov)
+                              : rhs_products<float>(po, 0, xstar, nullptr, M, false, fmu, nullptr, cov);
+}
+
+int gpc_quad(gpc_post* po, const double* mu, const double* sigma, int M, int compute_var, double* zalpha,
+             double* zKz) {
+  if (!po) return -2;
+  gpc_ctx* c = po->ctx;
+  if (!mu || !sigma || !zalpha || M <= 0 || (compute_var && !zKz)) FAIL(c, "gpc_quad: bad arguments");
+  if (po->cd.kind != K_SE && po->cd.kind != K_SE_ISO)
+    FAIL(c, "Bayesian quadrature only supports the squared exponential kernel.");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = po->dtype == GPC_F64
+               ? rhs_products<double>(po, 1, mu, sigma, M, compute_var != 0, zalpha, zKz, nullptr)
+               : rhs_products<float>(po, 1, mu, sigma, M, compute_var != 0, zalpha, zKz, nullptr);
+  if (rc || !compute_var) return rc;
+  // z (K + sn2_eff I)^-1 z^T: |W z|^2 / sl (L_chol) or -(z . L z) (L = -inv)   (:1946-1962)
+  for (int s = 0; s < po->S; ++s) {
+    const double sl = po->sp[(size_t)s * SP_STRIDE + SP_SL];
+    for (int j = 0; j < M; ++j) {
+      double& q = zKz[(size_t)j * po->S + s];
+      q = po->lchol[s] ? q / sl : -q;
+    }
+  }
+  return 0;
 }
 
 int gpc_last_timing(gpc_ctx* c, double* ms_total, double* ms_factor) {

@@ -784,6 +784,89 @@ class GP:
             return mu, s2, lpd
         return mu, s2
 
+    def predict_full(self, x_star, y_star=None, s2_star=None, add_noise: bool = False):
+        """Posterior mean and FULL covariance per hyperparameter sample (reference :1561-1661):
+        mu (M, S), cov (M, M, S).  K**, Ks, V = L^-T Ks and K** - V^T V are device products."""
+        x_star, y_star, s2_star = self._convert_shapes(x_star, y_star, s2_star)
+        s_N = self.posteriors.size
+        N_star, _ = x_star.shape
+        cov_N, noise_N, mean_N = self._counts()
+        mu = np.zeros((N_star, s_N))
+        cov = np.zeros((s_N, N_star, N_star))
+        if self.y is not None:
+            if self._post_handle is None:
+                raise ValueError("posteriors have been cleaned; call update() first")
+            self._ctx()
+            fmu, fcov = self._post_handle.predict_full(x_star)
+        for s in range(s_N):
+            hyp = self.posteriors[s].hyp
+            m_star = np.reshape(
+                self.mean.compute(hyp[cov_N + noise_N:cov_N + noise_N + mean_N], x_star), (-1,))
+            if self.y is None:  # no data: the prior
+                mu[:, s] = m_star
+                C = self.covariance.compute(hyp[0:cov_N], x_star)
+            else:
+                mu[:, s] = m_star + fmu[:, s]
+                C = fcov[s]
+            C = (C + C.T) / 2  # :1647
+            cov[s, :, :] = C
+            if add_noise:
+                sn2_mult = self.posteriors[s].sn2_mult
+                if sn2_mult is None:
+                    sn2_mult = 1
+                sn2_star = self.noise.compute(hyp[cov_N:cov_N + noise_N], x_star, y_star, s2_star)
+                cov[s, :, :] += np.dot(np.eye(N_star), sn2_star) * sn2_mult  # :1659, verbatim semantics
+        return mu, cov.transpose(1, 2, 0)
+
+    def quad(self, mu, sigma, compute_var: bool = False, separate_samples: bool = False):
+        """Bayesian quadrature of the GP against Gaussian measures N(mu_j, diag(sigma_j^2))
+        (reference :1818-1981; squared-exponential kernels only).  The kernel-mean vectors z,
+        z.alpha and z (K + sn2 I)^-1 z^T are computed on the device for all samples."""
+        from .covariance_functions import SquaredExponential
+        from .mean_functions import NegativeQuadratic, ZeroMean
+
+        if not isinstance(self.covariance, SquaredExponential):
+            raise ValueError("Bayesian quadrature only supports the squared exponential kernel.")
+        N, D = self.X.shape
+        N_s = np.size(self.posteriors)
+        cov_N, noise_N, _ = self._counts()
+        mu = np.tile(mu, (1, D)) if np.size(mu) == 1 else np.atleast_2d(np.asarray(mu, dtype=float))
+        N_star = mu.shape[0]
+        sigma = np.tile(sigma, (1, D)) if np.size(sigma) == 1 else np.atleast_2d(np.asarray(sigma, dtype=float))
+        sigma = np.broadcast_to(sigma, mu.shape).astype(float)
+        if self._post_handle is None:
+            raise ValueError("posteriors have been cleaned; call update() first")
+        self._ctx()
+        za, zkz = self._post_handle.quad(mu, sigma, compute_var)
+        quadratic = isinstance(self.mean, NegativeQuadratic)
+        F = np.zeros((N_star, N_s))
+        F_var = np.zeros((N_star, N_s)) if compute_var else None
+        iso = cov_N == 2 and D != 1
+        for s in range(N_s):
+            hyp = self.posteriors[s].hyp
+            ell = np.exp(hyp[0]) * np.ones(D) if iso else np.exp(hyp[0:D])
+            ln_sf2 = 2 * hyp[cov_N - 1]
+            sum_lnell = np.sum(np.log(ell))
+            m0 = 0 if isinstance(self.mean, ZeroMean) else hyp[cov_N + noise_N]
+            F[:, s] = za[:, s] + m0
+            if quadratic:
+                xm = hyp[cov_N + noise_N + 1:cov_N + noise_N + D + 1]
+                omega = np.exp(hyp[cov_N + noise_N + D + 1:])
+                F[:, s] += -0.5 * np.sum(1 / omega**2 * (mu**2 + sigma**2 - 2 * mu * xm + xm**2), 1)
+            if compute_var:
+                tau_kk = np.sqrt(2 * sigma**2 + ell**2)
+                nf_kk = np.exp(ln_sf2 + sum_lnell - np.sum(np.log(tau_kk), 1))
+                F_var[:, s] = np.maximum(np.spacing(1), nf_kk - zkz[:, s])
+        if N_s > 1 and not separate_samples:
+            F_bar = np.reshape(np.sum(F, 1), (-1, 1)) / N_s
+            if compute_var:
+                Fss_var = np.sum((F - F_bar) ** 2, 1) / (N_s - 1)
+                F_var = np.reshape(np.sum(F_var, 1) / N_s + Fss_var, (-1, 1))
+            F = F_bar
+        if compute_var:
+            return F, F_var
+        return F
+
     # ------------------------------------------------------------------ misc
     def _convert_shapes(self, X, y, s2):
         """Reference :2523-2565."""

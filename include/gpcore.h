@@ -97,6 +97,19 @@ int gpc_post_free(gpc_post* post);
  *   fs2[j*S + s]  = kss - colsum(V*V)   or   kss + colsum(Ks * (L Ks))   (unclamped) */
 int gpc_predict(gpc_post* post, const double* xstar, int M, double* fmu, double* fs2);
 
+/* ---- GP.predict_full (gaussian_process.py:1603-1650) -------------------------------------
+ * fmu[j*S + s] = Ks^T alpha;  cov[s] (M x M, row-major) = K** - V^T V  or  K** + Ks^T (L Ks)
+ * (the caller symmetrises and adds noise, :1647-1659).                                    */
+int gpc_predict_full(gpc_post* post, const double* xstar, int M, double* fmu, double* cov);
+
+/* ---- GP.quad: Bayesian quadrature products (gaussian_process.py:1908-1966), SE kernels ----
+ * mu, sigma: M x D (means and standard deviations of the Gaussian measures).  With z the
+ * kernel mean vector of measure j under sample s:
+ *   zalpha[j*S + s] = z . alpha                      (the caller adds the mean-function terms)
+ *   zKz[j*S + s]    = z (K + sn2_eff I)^-1 z^T       (only if compute_var)                  */
+int gpc_quad(gpc_post* post, const double* mu, const double* sigma, int M, int compute_var,
+             double* zalpha, double* zKz);
+
 /* ---- instrumentation -------------------------------------------------------------
  * GPU time (ms, hipEvent on the library's stream) of the last gpc_nll_batch /
  * gpc_posterior_batch: whole device section, and the part spent in the MFMA GEMM

@@ -12,6 +12,7 @@ Files written next to this script:
   cov_cases.npz    covariance.compute(): K, dK, K(X,X*), diag for every kernel
   core_cases.npz   GP.__compute_nlZ (nlZ, dnlZ), Posterior fields, GP.predict
   prior_cases.npz  GP.__compute_log_priors, normalization constants, f_min_fill designs
+  full_cases.npz   GP.predict_full (with and without noise) and GP.quad
   fit_cases.npz    GP.fit end to end under a fixed global seed (hyp samples, predictions)
 """
 
@@ -326,8 +327,59 @@ def fit_cases():
     np.savez_compressed(os.path.join(HERE, "fit_cases.npz"), **out)
 
 
+def full_cases():
+    """GP.predict_full and GP.quad from the reference."""
+    out = {}
+    names = []
+    cases = [("se", "const", (1, 0, 0), 33, 2), ("se", "negquad", (1, 0, 0), 130, 3),
+             ("se", "zero", (0, 0, 0), 33, 2), ("matern5", "const", (1, 1, 0), 40, 2),
+             ("se", "const", (1, 0, 0), 200, 1)]
+    for idx, (kname, mname, npar, N, D) in enumerate(cases):
+        rng = np.random.default_rng(15000 + idx)
+        cov, mean, noise = KERNELS[kname](), MEANS[mname](), make_noise(npar)
+        gp = gpr.GP(D=D, covariance=cov, mean=mean, noise=noise)
+        cov_N, mean_N, noise_N = cov.hyperparameter_count(D), mean.hyperparameter_count(D), noise.hyperparameter_count()
+        X = rng.uniform(-3, 3, (N, D))
+        y = np.sin(np.sum(X, 1, keepdims=True) / np.sqrt(D)) + 0.1 * rng.standard_normal((N, 1))
+        s2 = 0.01 + 0.05 * rng.uniform(size=(N, 1)) if npar[1] else None
+        S = 3
+        hyp = np.zeros((S, cov_N + noise_N + mean_N))
+        for s in range(S):
+            h_cov = 0.2 * rng.standard_normal(cov_N)
+            h_cov[:D] += np.log(1.2 * np.sqrt(D))
+            h_noise = [np.log(0.1) + 0.2 * rng.standard_normal()] if npar[0] else []
+            h_mean = {"zero": [], "const": [0.2 * rng.standard_normal()]}.get(
+                mname, [0.2 * rng.standard_normal()] + list(0.5 * rng.standard_normal(D))
+                + list(np.log(4.0) + 0.2 * rng.standard_normal(D)))
+            hyp[s] = np.concatenate([h_cov, h_noise, h_mean])
+        gp.update(X_new=X, y_new=y, s2_new=s2, hyp=hyp)
+        M = 9
+        xs = rng.uniform(-3.5, 3.5, (M, D))
+        tag = f"u{idx:03d}"
+        names.append(f"{tag}|{kname}|{mname}|{npar[0]}{npar[1]}{npar[2]}|{N}|{D}")
+        out[tag + "_X"], out[tag + "_y"], out[tag + "_hyp"], out[tag + "_xs"] = X, y, hyp, xs
+        if s2 is not None:
+            out[tag + "_s2"] = s2
+        s2s = 0.02 * np.ones((M, 1)) if s2 is not None else None
+        mu, C = gp.predict_full(xs, None, s2s, add_noise=False)
+        out[tag + "_pf_mu"], out[tag + "_pf_cov"] = mu, C
+        mu, C = gp.predict_full(xs, None, s2s, add_noise=True)
+        out[tag + "_pf_cov_noise"] = C
+        if kname == "se" and npar[0] == 1:  # the reference's quad indexes the constant-noise entry
+            qm = rng.uniform(-1, 1, (5, D))
+            qs = 0.3 + rng.uniform(size=(5, D))
+            F, Fv = gp.quad(qm, qs, compute_var=True, separate_samples=True)
+            Fa, Fva = gp.quad(qm, qs, compute_var=True)
+            out[tag + "_qm"], out[tag + "_qs"] = qm, qs
+            out[tag + "_F"], out[tag + "_Fv"], out[tag + "_Fa"], out[tag + "_Fva"] = F, Fv, Fa, Fva
+            out[tag + "_F1"] = gp.quad(0.1, 0.5)
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "full_cases.npz"), **out)
+    print("full cases:", len(names))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["cov", "core", "prior", "fit"]
+    which = sys.argv[1:] or ["cov", "core", "prior", "fit", "full"]
     if "cov" in which:
         cov_cases()
     if "core" in which:
@@ -336,4 +388,6 @@ if __name__ == "__main__":
         prior_cases()
     if "fit" in which:
         fit_cases()
+    if "full" in which:
+        full_cases()
     sys.exit(0)

@@ -69,3 +69,17 @@ def test_fit_recovers_generating_hyperparameters():
     assert np.abs(hyp[0, :3] - hyp_true[0, :3]).max() < 0.5
     ll_fit, ll_true = gp.log_likelihood(hyp[0]), gp.log_likelihood(hyp_true[0])
     assert ll_fit >= ll_true - 1e-6 and ll_fit - ll_true < 20
+
+
+def test_example_script_runs_end_to_end():
+    """BASELINE config 1 (plumbing): the example runs through fit/predict/update."""
+    import importlib.util
+
+    path = os.path.join(os.path.dirname(os.path.dirname(__file__)), "examples", "fit_predict_2d.py")
+    spec = importlib.util.spec_from_file_location("fit_predict_2d", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    gp, fmu, fs2, fmu2, fs22 = mod.main(verbose=False)
+    assert fmu.shape == (400, 1) and fs2.shape == (400, 1) and np.all(fs2 >= 0)
+    assert gp.X.shape == (40, 2) and gp.posteriors.size == 10
+    assert np.sqrt(fs22).mean() < np.sqrt(fs2).mean()  # more data, less uncertainty
