@@ -52,15 +52,15 @@ struct GemmArgs {
 };
 inline int g_gemm_flags = 0;
 
-template <typename T, bool KM, int BT>
-__device__ __forceinline__ void g2r(typename MM<T>::vec_t (&r)[(BT * BKT) / (256 * MM<T>::VEC)],
+template <typename T, bool KM, int BT, int NT>
+__device__ __forceinline__ void g2r(typename MM<T>::vec_t (&r)[(BT * BKT) / (NT * MM<T>::VEC)],
                                     const T* __restrict__ g, int ld, int r0, int k0, int t) {
   using vec_t = typename MM<T>::vec_t;
   constexpr int VEC = MM<T>::VEC;
-  constexpr int NV = (BT * BKT) / (256 * VEC);
+  constexpr int NV = (BT * BKT) / (NT * VEC);
   if constexpr (!KM) {  // stored [row][k]
     constexpr int TPR = BKT / VEC;   // threads per row
-    constexpr int RPP = 256 / TPR;   // rows per pass
+    constexpr int RPP = NT / TPR;    // rows per pass
 #pragma unroll
     for (int p = 0; p < NV; ++p) {
       const int row = t / TPR + p * RPP;
@@ -71,7 +71,7 @@ __device__ __forceinline__ void g2r(typename MM<T>::vec_t (&r)[(BT * BKT) / (256
     constexpr int VPR = BT / VEC;  // vectors per k-row
 #pragma unroll
     for (int p = 0; p < NV; ++p) {
-      const int v = t + 256 * p;
+      const int v = t + NT * p;
       const int k = v / VPR;
       const int mc = (v % VPR) * VEC;
       r[p] = *reinterpret_cast<const vec_t*>(g + (size_t)(k0 + k) * ld + r0 + mc);
@@ -79,17 +79,17 @@ __device__ __forceinline__ void g2r(typename MM<T>::vec_t (&r)[(BT * BKT) / (256
   }
 }
 
-template <typename T, bool KM, int BT>
+template <typename T, bool KM, int BT, int NT>
 __device__ __forceinline__ void r2s(T* __restrict__ s,
-                                    const typename MM<T>::vec_t (&r)[(BT * BKT) / (256 * MM<T>::VEC)],
+                                    const typename MM<T>::vec_t (&r)[(BT * BKT) / (NT * MM<T>::VEC)],
                                     int t) {
   using vec_t = typename MM<T>::vec_t;
   constexpr int VEC = MM<T>::VEC;
-  constexpr int NV = (BT * BKT) / (256 * VEC);
+  constexpr int NV = (BT * BKT) / (NT * VEC);
   constexpr int LDP = ldp_of(BT);
   if constexpr (!KM) {
     constexpr int TPR = BKT / VEC;
-    constexpr int RPP = 256 / TPR;
+    constexpr int RPP = NT / TPR;
 #pragma unroll
     for (int p = 0; p < NV; ++p) {
       const int row = t / TPR + p * RPP;
@@ -101,7 +101,7 @@ __device__ __forceinline__ void r2s(T* __restrict__ s,
     constexpr int VPR = BT / VEC;
 #pragma unroll
     for (int p = 0; p < NV; ++p) {
-      const int v = t + 256 * p;
+      const int v = t + NT * p;
       const int k = v / VPR;
       const int mc = (v % VPR) * VEC;
       *reinterpret_cast<vec_t*>(s + k * LDP + mc) = r[p];
@@ -127,18 +127,23 @@ __device__ __forceinline__ void tri_tile(int tile, int& ti, int& tj) {
 
 // BT = block tile (128: 4 waves x 64x64; 64: 4 waves x 32x32, for launches too small to
 // fill 256 CUs with 128-tiles).  Triangular k-ranges stay 128-granular in both.
-template <typename T, bool AKM, bool BKM, int BT>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
+// NW = waves per block: 4 (2 x 2 waves of BT/2 x BT/2) or 8 (2 x 4 waves of BT/2 x BT/4:
+// half the accumulators per wave, so twice the waves per SIMD to cover staging and barriers).
+template <typename T, bool AKM, bool BKM, int BT, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(GemmArgs g) {
   using acc_t = typename MM<T>::acc_t;
   using vec_t = typename MM<T>::vec_t;
-  constexpr int NV = (BT * BKT) / (256 * MM<T>::VEC);
+  constexpr int NT = 64 * NW;
+  constexpr int NV = (BT * BKT) / (NT * MM<T>::VEC);
   constexpr int OPSZ = opsz_of(BT);
-  constexpr int WT = BT / 2;   // wave tile
-  constexpr int MR = BT / 32;  // 16x16 MFMA tiles per wave per dimension
+  constexpr int WCOLS = NW / 2;        // waves along n
+  constexpr int WTM = BT / 2;          // wave tile rows
+  constexpr int WTN = BT / WCOLS;      // wave tile cols
+  constexpr int MRM = WTM / 16, MRN = WTN / 16;
   __shared__ __attribute__((aligned(16))) T smem[4 * OPSZ];
 
   const int t = threadIdx.x;
-  const int lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
+  const int lane = t & 63, w = t >> 6, wr = w / WCOLS, wc = w % WCOLS;
 
   // Tile order = dispatch order.  Tiles differ in k-length when the k-range is
   // triangular, so the longest tiles go first (LPT) and the short ones fill the tail;
@@ -172,18 +177,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   const T* __restrict__ B = reinterpret_cast<const T*>(g.B) + (size_t)blockIdx.y * g.sB;
   T* __restrict__ C = reinterpret_cast<T*>(g.C) + (size_t)blockIdx.y * g.sC;
 
-  acc_t acc[MR][MR];
+  acc_t acc[MRM][MRN];
 #pragma unroll
-  for (int i = 0; i < MR; ++i)
+  for (int i = 0; i < MRM; ++i)
 #pragma unroll
-    for (int j = 0; j < MR; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+    for (int j = 0; j < MRN; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
 
   if (nk > 0) {
     vec_t ra[NV], rb[NV];
-    g2r<T, AKM, BT>(ra, A, g.lda, m0, k0, t);
-    g2r<T, BKM, BT>(rb, B, g.ldb, n0, k0, t);
-    r2s<T, AKM, BT>(smem, ra, t);
-    r2s<T, BKM, BT>(smem + OPSZ, rb, t);
+    g2r<T, AKM, BT, NT>(ra, A, g.lda, m0, k0, t);
+    g2r<T, BKM, BT, NT>(rb, B, g.ldb, n0, k0, t);
+    r2s<T, AKM, BT, NT>(smem, ra, t);
+    r2s<T, BKM, BT, NT>(smem + OPSZ, rb, t);
     __syncthreads();
     for (int it = 0; it < nk; ++it) {
       const int cur = it & 1;
@@ -191,28 +196,28 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
       const T* b_s = a_s + OPSZ;
       const bool more = (it + 1 < nk);
       if (more && !(g.flags & 4)) {
-        g2r<T, AKM, BT>(ra, A, g.lda, m0, k0 + (it + 1) * BKT, t);
-        g2r<T, BKM, BT>(rb, B, g.ldb, n0, k0 + (it + 1) * BKT, t);
+        g2r<T, AKM, BT, NT>(ra, A, g.lda, m0, k0 + (it + 1) * BKT, t);
+        g2r<T, BKM, BT, NT>(rb, B, g.ldb, n0, k0 + (it + 1) * BKT, t);
       }
       if (g.flags & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int kk = 0; kk < BKT; kk += 4) {
-        T af[MR], bf[MR];
+        T af[MRM], bf[MRN];
 #pragma unroll
-        for (int i = 0; i < MR; ++i) af[i] = frag<T, AKM, BT>(a_s, wr * WT + i * 16, kk, lane);
+        for (int i = 0; i < MRM; ++i) af[i] = frag<T, AKM, BT>(a_s, wr * WTM + i * 16, kk, lane);
 #pragma unroll
-        for (int j = 0; j < MR; ++j) bf[j] = frag<T, BKM, BT>(b_s, wc * WT + j * 16, kk, lane);
+        for (int j = 0; j < MRN; ++j) bf[j] = frag<T, BKM, BT>(b_s, wc * WTN + j * 16, kk, lane);
 #pragma unroll
-        for (int i = 0; i < MR; ++i)
+        for (int i = 0; i < MRM; ++i)
 #pragma unroll
-          for (int j = 0; j < MR; ++j) acc[i][j] = MM<T>::mma(af[i], bf[j], acc[i][j]);
+          for (int j = 0; j < MRN; ++j) acc[i][j] = MM<T>::mma(af[i], bf[j], acc[i][j]);
       }
       if (g.flags & 1) __builtin_amdgcn_s_setprio(0);
       if (g.flags & 2) continue;
       if (more) {
         T* a_n = smem + (cur ^ 1) * 2 * OPSZ;
-        r2s<T, AKM, BT>(a_n, ra, t);
-        r2s<T, BKM, BT>(a_n + OPSZ, rb, t);
+        r2s<T, AKM, BT, NT>(a_n, ra, t);
+        r2s<T, BKM, BT, NT>(a_n + OPSZ, rb, t);
       }
       __syncthreads();
     }
@@ -220,13 +225,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 
   const T alpha = (T)g.alpha;
 #pragma unroll
-  for (int i = 0; i < MR; ++i)
+  for (int i = 0; i < MRM; ++i)
 #pragma unroll
-    for (int j = 0; j < MR; ++j)
+    for (int j = 0; j < MRN; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wr * WT + i * 16 + MM<T>::row_of(lane, r);
-        const int col = n0 + wc * WT + j * 16 + (lane & 15);
+        const int row = m0 + wr * WTM + i * 16 + MM<T>::row_of(lane, r);
+        const int col = n0 + wc * WTN + j * 16 + (lane & 15);
         T* p = C + (size_t)row * g.ldc + col;
         T v = alpha * acc[i][j][r];
         if (g.beta) v += *p;
@@ -234,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
       }
 }
 
-template <typename T, int BT>
+template <typename T, int BT, int NW>
 inline hipError_t launch_gemm_bt(hipStream_t st, GemmArgs g, bool akm, bool bkm, int batch) {
   const int tm = g.M / BT, tn = g.N / BT;
   g.tiles_m = tm;
@@ -242,15 +247,15 @@ inline hipError_t launch_gemm_bt(hipStream_t st, GemmArgs g, bool akm, bool bkm,
   g.flags = g_gemm_flags;
   const int ntiles = g.lower_only ? tm * (tm + 1) / 2 : tm * tn;
   if (ntiles <= 0 || batch <= 0) return hipSuccess;
-  dim3 grid(ntiles, batch), block(256);
+  dim3 grid(ntiles, batch), block(64 * NW);
   if (!akm && !bkm)
-    hipLaunchKernelGGL((gemm_kernel<T, false, false, BT>), grid, block, 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<T, false, false, BT, NW>), grid, block, 0, st, g);
   else if (!akm && bkm)
-    hipLaunchKernelGGL((gemm_kernel<T, false, true, BT>), grid, block, 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<T, false, true, BT, NW>), grid, block, 0, st, g);
   else if (akm && bkm)
-    hipLaunchKernelGGL((gemm_kernel<T, true, true, BT>), grid, block, 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<T, true, true, BT, NW>), grid, block, 0, st, g);
   else
-    hipLaunchKernelGGL((gemm_kernel<T, true, false, BT>), grid, block, 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<T, true, false, BT, NW>), grid, block, 0, st, g);
   return hipGetLastError();
 }
 
@@ -258,13 +263,15 @@ inline hipError_t launch_gemm_bt(hipStream_t st, GemmArgs g, bool akm, bool bkm,
 // a quarter of the work each): the deep levels of the recursion are latency-, not
 // throughput-bound.  force_bt: 0 = choose, 64 / 128 = as given (tests).
 inline int g_small_launch_blocks = 1100;  // tunable: GPC_SMALL_BLOCKS
+inline int g_gemm_waves = 4;              // tunable: GPC_GEMM_WAVES (4 or 8) for 128-tiles
 template <typename T>
 inline hipError_t launch_gemm(hipStream_t st, GemmArgs g, bool akm, bool bkm, int batch, int force_bt = 0) {
   const int tm = g.M / TILE, tn = g.N / TILE;
   const long long blocks128 = (long long)(g.lower_only ? tm * (tm + 1) / 2 : tm * tn) * batch;
   const bool small = force_bt ? (force_bt == 64) : (blocks128 < g_small_launch_blocks);
-  if (small) return launch_gemm_bt<T, 64>(st, g, akm, bkm, batch);
-  return launch_gemm_bt<T, 128>(st, g, akm, bkm, batch);
+  if (small) return launch_gemm_bt<T, 64, 4>(st, g, akm, bkm, batch);
+  if (g_gemm_waves == 8) return launch_gemm_bt<T, 128, 8>(st, g, akm, bkm, batch);
+  return launch_gemm_bt<T, 128, 4>(st, g, akm, bkm, batch);
 }
 
 // algorithmic flops of one launch (for the roofline bookkeeping)

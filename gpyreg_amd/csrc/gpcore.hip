@@ -62,6 +62,11 @@ struct gpc_ctx {
   hipEvent_t ev_up = nullptr, ev_done[MAXG] = {}, ev_half[MAXG] = {};
   int groups = 2;
   int stagger = 0;  // group g starts when group g-1 has factored its left half
+  // side streams for the deferred trtri products (plan.h), per group and recursion depth
+  static constexpr int MAXD = 8;
+  hipStream_t sst[MAXG + 1][MAXD] = {};
+  hipEvent_t ev_fork[MAXG + 1][MAXD] = {}, ev_join[MAXG + 1][MAXD] = {};
+  int defer = 0, defer_min = 512;  // measured slower on MI355X/ROCm 7.2
   std::string err;
   std::string devinfo;
   // resident training data
@@ -248,7 +253,8 @@ struct Pipe {
 
   // Device kernels for `n` samples of the current chunk starting at chunk index `off`
   // (all per-sample buffers are indexed by chunk position), issued on stream `st`.
-  int device_section(hipStream_t st, int off, int n, hipEvent_t f0, hipEvent_t f1, hipEvent_t half = nullptr) {
+  int device_section(hipStream_t st, int off, int n, hipEvent_t f0, hipEvent_t f1, hipEvent_t half = nullptr,
+                     int gidx = gpc_ctx::MAXG) {
     Batch& b = *B;
     const int npad = b.npad, N = b.N, D = b.D;
     T* Ac = A + (size_t)off * sM;
@@ -285,6 +291,12 @@ struct Pipe {
     F.logdet = d_logdet;
     F.info = d_info;
     F.half_event = half;
+    if (c->defer && npad >= 2 * c->defer_min) {
+      F.side = c->sst[gidx];
+      F.ev_fork = c->ev_fork[gidx];
+      F.ev_join = c->ev_join[gidx];
+      F.defer_min = c->defer_min;
+    }
     // NLL only: the inverse of the whole matrix is not needed (only of left children)
     const bool full_inv = (mode != MODE_NLL);
     F.potrf_inv(0, npad, full_inv, mode == MODE_POST);
@@ -407,7 +419,7 @@ struct Pipe {
         HIPCHK(c, hipStreamWaitEvent(sg, c->ev_up, 0));
         if (c->stagger && g > 0) HIPCHK(c, hipStreamWaitEvent(sg, c->ev_half[g - 1], 0));
         int rc = device_section(sg, lo, hi - lo, g == 0 ? c->ev[1] : nullptr, nullptr,
-                                c->stagger ? c->ev_half[g] : nullptr);
+                                c->stagger ? c->ev_half[g] : nullptr, g);
         if (rc) return rc;
         HIPCHK(c, hipEventRecord(c->ev_done[g], sg));
         HIPCHK(c, hipStreamWaitEvent(st, c->ev_done[g], 0));
@@ -942,7 +954,9 @@ int gpc_create(int device, gpc_ctx** out) {
              prop.totalGlobalMem / 1073741824.0, prop.sharedMemPerBlock / 1024);
     c->devinfo = buf;
   }
-  if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess) {
+  int prio_lo = 0, prio_hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // lo = least, hi = greatest priority
+  if (hipStreamCreateWithPriority(&c->st, hipStreamNonBlocking, prio_hi) != hipSuccess) {
     g_create_err = "hipStreamCreate failed";
     delete c;
     return -1;
@@ -954,8 +968,13 @@ int gpc_create(int device, gpc_ctx** out) {
       return -1;
     }
   bool ok = hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming) == hipSuccess;
+  for (int g = 0; g <= gpc_ctx::MAXG && ok; ++g)
+    for (int d = 0; d < gpc_ctx::MAXD && ok; ++d)
+      ok = hipStreamCreateWithPriority(&c->sst[g][d], hipStreamNonBlocking, prio_lo) == hipSuccess &&
+           hipEventCreateWithFlags(&c->ev_fork[g][d], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&c->ev_join[g][d], hipEventDisableTiming) == hipSuccess;
   for (int g = 0; g < gpc_ctx::MAXG && ok; ++g)
-    ok = hipStreamCreateWithFlags(&c->gst[g], hipStreamNonBlocking) == hipSuccess &&
+    ok = hipStreamCreateWithPriority(&c->gst[g], hipStreamNonBlocking, prio_hi) == hipSuccess &&
          hipEventCreateWithFlags(&c->ev_done[g], hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&c->ev_half[g], hipEventDisableTiming) == hipSuccess;
   if (!ok) {
@@ -967,6 +986,9 @@ int gpc_create(int device, gpc_ctx** out) {
   if (const char* e = getenv("GPC_SMALL_BLOCKS")) gpc::g_small_launch_blocks = atoi(e);
   if (const char* e = getenv("GPC_GEMM_FLAGS")) gpc::g_gemm_flags = atoi(e);
   if (const char* e = getenv("GPC_LEAF")) gpc::g_leaf_version = atoi(e);
+  if (const char* e = getenv("GPC_GEMM_WAVES")) gpc::g_gemm_waves = atoi(e);
+  if (const char* e = getenv("GPC_DEFER")) c->defer = atoi(e);
+  if (const char* e = getenv("GPC_DEFER_MIN")) c->defer_min = atoi(e);
   if (const char* e = getenv("GPC_STAGGER")) c->stagger = atoi(e);
   *out = c;
   return 0;
@@ -984,6 +1006,12 @@ void gpc_destroy(gpc_ctx* c) {
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
   if (c->ev_up) (void)hipEventDestroy(c->ev_up);
+  for (int g = 0; g <= gpc_ctx::MAXG; ++g)
+    for (int d = 0; d < gpc_ctx::MAXD; ++d) {
+      if (c->ev_fork[g][d]) (void)hipEventDestroy(c->ev_fork[g][d]);
+      if (c->ev_join[g][d]) (void)hipEventDestroy(c->ev_join[g][d]);
+      if (c->sst[g][d]) (void)hipStreamDestroy(c->sst[g][d]);
+    }
   for (int g = 0; g < gpc_ctx::MAXG; ++g) {
     if (c->ev_done[g]) (void)hipEventDestroy(c->ev_done[g]);
     if (c->ev_half[g]) (void)hipEventDestroy(c->ev_half[g]);
