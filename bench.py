@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--dtype", default=None, choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nll-only", action="store_true", help="time NLL without gradient")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend (nccl = RCCL; gloo only to rehearse ranks on one GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -107,12 +109,18 @@ def main():
     import torch
 
     dist = None
-    if world > 1:
+    ndev = torch.cuda.device_count()
+    if args.backend == "gloo":
+        local_rank = local_rank % max(ndev, 1)  # rehearsal: ranks may share a GPU
+    torch.cuda.set_device(local_rank)
+    if "RANK" in os.environ and (world > 1 or os.environ.get("BENCH_FORCE_DIST")):
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+    dev = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")
 
     X, y, hyp = synthetic_problem(args.config, S, seed_shift=rank)
     gp = make_gp(args.config, dtype)
@@ -128,7 +136,7 @@ def main():
     def step():
         nonlocal gathered
         nlz, dnlz = gp.nll_batch(hyp, compute_grad=grad)
-        if world > 1:  # the one exchange step of the path: per-sample [nlZ | dnlZ]
+        if dist is not None:  # the one exchange step of the path: per-sample [nlZ | dnlZ]
             loc = np.concatenate([nlz[:, None], dnlz if grad else np.zeros((S, 0))], axis=1)
             t = torch.from_numpy(loc).to(dev)
             out = torch.empty((world * t.shape[0], t.shape[1]), dtype=t.dtype, device=dev)
@@ -137,7 +145,7 @@ def main():
         return nlz, dnlz
 
     def sync():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -153,10 +161,12 @@ def main():
         fac_ms.append(b)
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        if gathered is not None:  # every rank holds every sample's result
+            assert gathered.shape == (world * S, 1 + (hyp_N if grad else 0))
 
     if rank == 0:
         N = cfg["N"]
@@ -208,7 +218,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.config, X, y, hyp)
             out["vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 
