@@ -55,28 +55,40 @@ __global__ __launch_bounds__(256) void gemv_sub_kernel(const T* __restrict__ A_a
   if (lane == 0) r_all[(size_t)b * npad + i] -= s;
 }
 
-// out[b][k] = scale[b] * sum_{i>=k} W[b][i][k] * z[b][i]   (W^T z).  grid = (npad/64, batch)
-// scale[b] = 1/sp[b][SP_SL] when sp != nullptr.
+// W^T z in two deterministic passes.  Pass 1: part[b][ch][k] = sum over the rows of chunk ch
+// (TRC rows, only rows >= the diagonal tile of column k) of W[b][i][k] * z[b][i];
+// grid = (npad/64, npad/TRC, batch).  Pass 2: out[b][k] = scale[b] * sum_ch part (fixed order).
+constexpr int TRC = 128;  // = TILE, so every padded size is a whole number of chunks
 template <typename T>
-__global__ __launch_bounds__(256) void trmv_t_kernel(const T* __restrict__ W_all, long long sW, int ldw,
-                                                     const double* __restrict__ z_all, int npad,
-                                                     const double* __restrict__ sp_all, int sp_stride,
-                                                     int sp_off, double* __restrict__ out_all) {
+__global__ __launch_bounds__(256) void trmv_t_part_kernel(const T* __restrict__ W_all, long long sW, int ldw,
+                                                          const double* __restrict__ z_all, int npad,
+                                                          double* __restrict__ part_all) {
   __shared__ double red[4][64];
-  const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int b = blockIdx.z, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int k = blockIdx.x * 64 + lane;
-  const int istart = (blockIdx.x * 64) & ~127;
+  const int nch = npad / TRC;
+  const int r0 = blockIdx.y * TRC, r1 = r0 + TRC;
+  const int istart = max(r0, (int)((blockIdx.x * 64) & ~127));
   const T* Wb = W_all + (size_t)b * sW;
   const double* z = z_all + (size_t)b * npad;
   double s = 0.0;
-  for (int i = istart + w; i < npad; i += 4) s += (double)Wb[(size_t)i * ldw + k] * z[i];
+  for (int i = istart + w; i < r1; i += 4) s += (double)Wb[(size_t)i * ldw + k] * z[i];
   red[w][lane] = s;
   __syncthreads();
-  if (w == 0) {
-    double v = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
-    if (sp_all) v /= sp_all[(size_t)b * sp_stride + sp_off];
-    out_all[(size_t)b * npad + k] = v;
-  }
+  if (w == 0)
+    part_all[((size_t)b * nch + blockIdx.y) * npad + k] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+}
+
+// grid = (npad/128, batch), 128 threads; scale[b] = 1/sp[b][sp_off] when sp != nullptr
+__global__ __launch_bounds__(128) void trmv_t_sum_kernel(const double* __restrict__ part_all, int npad,
+                                                         const double* __restrict__ sp_all, int sp_stride,
+                                                         int sp_off, double* __restrict__ out_all) {
+  const int b = blockIdx.y, k = blockIdx.x * 128 + threadIdx.x;
+  const int nch = npad / TRC;
+  double v = 0.0;
+  for (int ch = k / TRC; ch < nch; ++ch) v += part_all[((size_t)b * nch + ch) * npad + k];
+  if (sp_all) v /= sp_all[(size_t)b * sp_stride + sp_off];
+  out_all[(size_t)b * npad + k] = v;
 }
 
 // out[b] = sum_i x[b][i] * y[b][i].   grid = (1, batch)

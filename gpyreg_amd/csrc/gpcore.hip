@@ -77,6 +77,7 @@ struct gpc_ctx {
   DevBuf mA, mW, mT;             // matrices of the current chunk
   DevBuf xs, spb, mulb, divb;    // scaled inputs and per-sample scalars
   DevBuf dvec, rvec, zvec, avec; // per-sample vectors (npad each)
+  DevBuf tpart;                  // W^T z partial sums
   DevBuf scal;                   // logdet | quad | (ints) info
   DevBuf parts, gout, diagq;     // trace pass
   DevBuf dmb, dsn2b, mg, ng;     // mean / noise gradient inputs and outputs
@@ -311,8 +312,11 @@ struct Pipe {
     hipLaunchKernelGGL(dot_kernel, dim3(1, n), dim3(256), 0, st, (const double*)zvec, (const double*)zvec,
                        npad, npad, d_quad);
     if (mode != MODE_NLL) {
-      hipLaunchKernelGGL((trmv_t_kernel<T>), dim3(npad / 64, n), dim3(256), 0, st, (const T*)Wc, sM, npad,
-                         (const double*)zvec, npad, (const double*)spb, (int)SP_STRIDE, (int)SP_SL, avec);
+      double* tpart = c->tpart.as<double>() + (size_t)off * (npad / TRC) * npad;
+      hipLaunchKernelGGL((trmv_t_part_kernel<T>), dim3(npad / 64, npad / TRC, n), dim3(256), 0, st, (const T*)Wc,
+                         sM, npad, (const double*)zvec, npad, tpart);
+      hipLaunchKernelGGL(trmv_t_sum_kernel, dim3(npad / 128, n), dim3(128), 0, st, (const double*)tpart, npad,
+                         (const double*)spb, (int)SP_STRIDE, (int)SP_SL, avec);
     }
     HIPCHK(c, hipGetLastError());
 
@@ -373,6 +377,7 @@ struct Pipe {
     HIPCHK(c, c->rvec.ensure(cnt * vb));
     HIPCHK(c, c->zvec.ensure(cnt * vb));
     HIPCHK(c, c->avec.ensure(cnt * vb));
+    HIPCHK(c, c->tpart.ensure((size_t)cnt * (npad / TRC + 1) * vb));
     HIPCHK(c, c->scal.ensure((size_t)cnt * (2 * sizeof(double) + sizeof(int)) + 64));
     double* d_logdet = c->scal.as<double>();
     double* d_quad = d_logdet + cnt;
@@ -468,6 +473,9 @@ struct Pipe {
 };
 
 size_t free_device_bytes() {
+  // GPC_MEM_BUDGET_MB caps what the library considers free (tests use it to force the
+  // sample-chunking paths)
+  if (const char* e = getenv("GPC_MEM_BUDGET_MB")) return (size_t)atoll(e) << 20;
   size_t f = 0, t = 0;
   if (hipMemGetInfo(&f, &t) != hipSuccess) return (size_t)8 << 30;
   return f;
@@ -478,7 +486,7 @@ int nll_impl(gpc_ctx* c, Batch& b, int want_grad, const double* dm, int mean_N, 
              int noise_N, double* nlz, double* dnlz, double* sn2_mult, int* L_chol, int* info) {
   const int S = b.S, npad = b.npad, N = b.N;
   const size_t per = 3ull * npad * npad * sizeof(T);
-  size_t budget = free_device_bytes() + c->mA.bytes + c->mW.bytes + c->mT.bytes;
+  size_t budget = free_device_bytes() + (getenv("GPC_MEM_BUDGET_MB") ? 0 : c->mA.bytes + c->mW.bytes + c->mT.bytes);
   budget = (size_t)(budget * 0.8);
   int chunk = (int)std::max<size_t>(1, std::min<size_t>(S, budget / per));
   HIPCHK(c, c->mA.ensure((size_t)chunk * npad * npad * sizeof(T)));
@@ -574,7 +582,7 @@ int post_impl(gpc_ctx* c, Batch& b, gpc_post* po, double* sn2_mult, int* L_chol,
   HIPCHK(c, po->A.ensure(S * msz));
   HIPCHK(c, po->W.ensure(S * msz));
   HIPCHK(c, po->alpha.ensure((size_t)S * npad * sizeof(double)));
-  size_t budget = (size_t)((free_device_bytes() + c->mT.bytes) * 0.8);
+  size_t budget = (size_t)((free_device_bytes() + (getenv("GPC_MEM_BUDGET_MB") ? 0 : c->mT.bytes)) * 0.8);
   int chunk = (int)std::max<size_t>(1, std::min<size_t>(S, budget / msz));
   HIPCHK(c, c->mT.ensure((size_t)chunk * msz));
 
@@ -666,7 +674,8 @@ int rhs_products(gpc_post* po, int mode, const double* xa, const double* xb, int
   const long long sKs = (long long)npad * mpad;
   const long long sKss = (long long)mpad * mpad;
   const size_t per = (2ull * npad * mpad + (full ? (size_t)mpad * mpad : 0)) * sizeof(T);
-  size_t budget = (size_t)((free_device_bytes() + c->ks.bytes + c->vb.bytes + c->kss.bytes) * 0.8);
+  size_t budget = (size_t)((free_device_bytes() +
+                            (getenv("GPC_MEM_BUDGET_MB") ? 0 : c->ks.bytes + c->vb.bytes + c->kss.bytes)) * 0.8);
   int chunk = (int)std::max<size_t>(1, std::min<size_t>(S, budget / per));
   HIPCHK(c, c->ks.ensure((size_t)chunk * sKs * sizeof(T)));
   HIPCHK(c, c->vb.ensure((size_t)chunk * sKs * sizeof(T)));
@@ -1001,7 +1010,7 @@ void gpc_destroy(gpc_ctx* c) {
   DevBuf* bufs[] = {&c->dX,   &c->mA,    &c->mW,  &c->mT,   &c->xs,   &c->spb,  &c->mulb, &c->divb,
                     &c->dvec, &c->rvec,  &c->zvec, &c->avec, &c->scal, &c->parts, &c->gout, &c->diagq,
                     &c->dmb,  &c->dsn2b, &c->mg,  &c->ng,   &c->ks,   &c->vb,   &c->xss,  &c->pout, &c->kss,
-                    &c->dbg1, &c->dbg2,  &c->dbg3};
+                    &c->dbg1, &c->dbg2,  &c->dbg3, &c->tpart};
   for (DevBuf* b : bufs) b->release();
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
