@@ -168,6 +168,20 @@ def main():
         if gathered is not None:  # every rank holds every sample's result
             assert gathered.shape == (world * S, 1 + (hyp_N if grad else 0))
 
+    # The dominant single kernel, timed alone: two extra UNTIMED steps with one sample group, so
+    # the W^T W launch (gemm_kernel<T,true,true,128,4>, all S samples in one grid) is not
+    # co-scheduled with another group's kernels and its hipEvent time is the kernel's duration.
+    lau_ms, lau_fl = [], 0.0
+    if rank == 0 and grad:
+        groups_env = int(os.environ.get("GPC_GROUPS", "2"))
+        ctx.set_option("groups", 1)
+        for _ in range(3):
+            gp.nll_batch(hyp, compute_grad=True)
+            lm, lau_fl = ctx.last_lauum_timing()
+            lau_ms.append(lm)
+        lau_ms = lau_ms[1:]
+        ctx.set_option("groups", groups_env)
+
     if rank == 0:
         N = cfg["N"]
         fits = S * args.steps * world
@@ -211,6 +225,15 @@ def main():
                 "launch_ms": fac * 1e3,
                 "device_ms_per_step": float(np.mean(tot_ms)),
                 "measured_mfma_ceiling": {"tflops": tf, "cycles_per_mfma_per_simd": cyc, "clock_ghz": ghz},
+                # the single dominant kernel (one launch per sample group): W^T W ("lauum"),
+                # gemm_kernel<T,true,true,128,4> in the rocprofv3 summary under profiles/
+                "dominant_kernel": None if not (grad and lau_fl > 0) else {
+                    "name": "gemm_kernel<T,true,true,128,4> (lauum: (K+sn2 I)^-1 = W^T W), all samples in one launch",
+                    "flops_per_launch": lau_fl,
+                    "launch_ms": float(np.mean(lau_ms)),
+                    "achieved": lau_fl / (float(np.mean(lau_ms)) * 1e-3) / 1e12,
+                    "frac": lau_fl / (float(np.mean(lau_ms)) * 1e-3) / 1e12 / peak,
+                },
             },
             "nlz_sample0": float(nlz[0]),
         }

@@ -51,6 +51,8 @@ SIGNATURES = {
     "gpc_predict_full": (C.c_int, [_vp, _dp, C.c_int, _dp, _dp]),
     "gpc_quad": (C.c_int, [_vp, _dp, _dp, C.c_int, C.c_int, _dp, _dp]),
     "gpc_last_timing": (C.c_int, [_vp, _dp, _dp]),
+    "gpc_last_lauum_timing": (C.c_int, [_vp, _dp, _dp]),
+    "gpc_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "gpc_mfma_peak": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
     "gpc_debug_gemm": (
         C.c_int,
@@ -203,6 +205,14 @@ class Context:
     def last_timing(self):
         a, b = C.c_double(), C.c_double()
         self._lib.gpc_last_timing(self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def set_option(self, name: str, value: int):
+        self._check(self._lib.gpc_set_option(self._h, name.encode(), int(value)), "gpc_set_option")
+
+    def last_lauum_timing(self):
+        a, b = C.c_double(), C.c_double()
+        self._lib.gpc_last_lauum_timing(self._h, C.byref(a), C.byref(b))
         return a.value, b.value
 
     def mfma_peak(self, dtype=F64):

@@ -239,6 +239,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(GemmArgs g) {
       }
 }
 
+inline int g_gemm_pad_lds = 0;  // experiment: extra dynamic LDS (bytes) on 128-tile launches
 template <typename T, int BT, int NW>
 inline hipError_t launch_gemm_bt(hipStream_t st, GemmArgs g, bool akm, bool bkm, int batch) {
   const int tm = g.M / BT, tn = g.N / BT;
@@ -248,14 +249,15 @@ inline hipError_t launch_gemm_bt(hipStream_t st, GemmArgs g, bool akm, bool bkm,
   const int ntiles = g.lower_only ? tm * (tm + 1) / 2 : tm * tn;
   if (ntiles <= 0 || batch <= 0) return hipSuccess;
   dim3 grid(ntiles, batch), block(64 * NW);
+  const unsigned dyn = (BT == 128) ? (unsigned)g_gemm_pad_lds : 0u;
   if (!akm && !bkm)
-    hipLaunchKernelGGL((gemm_kernel<T, false, false, BT, NW>), grid, block, 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<T, false, false, BT, NW>), grid, block, dyn, st, g);
   else if (!akm && bkm)
-    hipLaunchKernelGGL((gemm_kernel<T, false, true, BT, NW>), grid, block, 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<T, false, true, BT, NW>), grid, block, dyn, st, g);
   else if (akm && bkm)
-    hipLaunchKernelGGL((gemm_kernel<T, true, true, BT, NW>), grid, block, 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<T, true, true, BT, NW>), grid, block, dyn, st, g);
   else
-    hipLaunchKernelGGL((gemm_kernel<T, true, false, BT, NW>), grid, block, 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<T, true, false, BT, NW>), grid, block, dyn, st, g);
   return hipGetLastError();
 }
 

@@ -66,6 +66,9 @@ struct gpc_ctx {
   static constexpr int MAXD = 8;
   hipStream_t sst[MAXG + 1][MAXD] = {};
   hipEvent_t ev_fork[MAXG + 1][MAXD] = {}, ev_join[MAXG + 1][MAXD] = {};
+  hipEvent_t ev_l0[MAXG + 1] = {}, ev_l1[MAXG + 1] = {};  // around the lauum launch of each group
+  double ms_lauum = 0, flops_lauum = 0;  // slowest group's lauum launch of the last call
+  int lauum_groups = 0;
   int defer = 0, defer_min = 512;  // measured slower on MI355X/ROCm 7.2
   std::string err;
   std::string devinfo;
@@ -301,7 +304,12 @@ struct Pipe {
     // NLL only: the inverse of the whole matrix is not needed (only of left children)
     const bool full_inv = (mode != MODE_NLL);
     F.potrf_inv(0, npad, full_inv, mode == MODE_POST);
-    if (mode == MODE_GRAD) F.lauum(Tc, sM);
+    if (mode == MODE_GRAD) {
+      HIPCHK(c, hipEventRecord(c->ev_l0[gidx], st));
+      F.lauum(Tc, sM);
+      HIPCHK(c, hipEventRecord(c->ev_l1[gidx], st));
+      lauum_n[gidx] = n;
+    }
     HIPCHK(c, F.err);
     HIPCHK(c, hipGetLastError());
     if (f1) HIPCHK(c, hipEventRecord(f1, st));
@@ -343,6 +351,7 @@ struct Pipe {
   }
 
   int chunk_cnt = 0;
+  int lauum_n[gpc_ctx::MAXG + 1] = {};
 
   // run the device pipeline for samples [s0, s0+cnt) whose matrices start at slot `slot`.
   // The chunk is split into sample groups on separate HIP streams: the latency-bound
@@ -454,6 +463,18 @@ struct Pipe {
     (void)hipEventElapsedTime(&t12, c->ev[1], c->ev[2]);
     c->ms_total += t03;
     c->ms_factor += t12;
+    if (mode == MODE_GRAD) {  // the dominant single kernel: the lauum launch of each group
+      for (int g = 0; g <= gpc_ctx::MAXG; ++g)
+        if (lauum_n[g] > 0) {
+          float t = 0;
+          (void)hipEventElapsedTime(&t, c->ev_l0[g], c->ev_l1[g]);
+          if (t > c->ms_lauum) {
+            c->ms_lauum = t;
+            c->flops_lauum = (double)lauum_n[g] * (double)b.N * b.N * b.N / 3.0;
+          }
+          lauum_n[g] = 0;
+        }
+    }
     return 0;
   }
 
@@ -513,6 +534,7 @@ int nll_impl(gpc_ctx* c, Batch& b, int want_grad, const double* dm, int mean_N, 
   p.ng.assign((size_t)S * std::max(noise_N, 1), 0.0);
 
   c->ms_total = c->ms_factor = 0;
+  c->ms_lauum = c->flops_lauum = 0;
   c->last_flops = 0;
   for (int s0 = 0; s0 < S; s0 += chunk) {
     const int cnt = std::min(chunk, S - s0);
@@ -978,6 +1000,8 @@ int gpc_create(int device, gpc_ctx** out) {
     }
   bool ok = hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming) == hipSuccess;
   for (int g = 0; g <= gpc_ctx::MAXG && ok; ++g)
+    ok = hipEventCreate(&c->ev_l0[g]) == hipSuccess && hipEventCreate(&c->ev_l1[g]) == hipSuccess;
+  for (int g = 0; g <= gpc_ctx::MAXG && ok; ++g)
     for (int d = 0; d < gpc_ctx::MAXD && ok; ++d)
       ok = hipStreamCreateWithPriority(&c->sst[g][d], hipStreamNonBlocking, prio_lo) == hipSuccess &&
            hipEventCreateWithFlags(&c->ev_fork[g][d], hipEventDisableTiming) == hipSuccess &&
@@ -996,6 +1020,7 @@ int gpc_create(int device, gpc_ctx** out) {
   if (const char* e = getenv("GPC_GEMM_FLAGS")) gpc::g_gemm_flags = atoi(e);
   if (const char* e = getenv("GPC_LEAF")) gpc::g_leaf_version = atoi(e);
   if (const char* e = getenv("GPC_GEMM_WAVES")) gpc::g_gemm_waves = atoi(e);
+  if (const char* e = getenv("GPC_GEMM_PADLDS")) gpc::g_gemm_pad_lds = atoi(e);
   if (const char* e = getenv("GPC_DEFER")) c->defer = atoi(e);
   if (const char* e = getenv("GPC_DEFER_MIN")) c->defer_min = atoi(e);
   if (const char* e = getenv("GPC_STAGGER")) c->stagger = atoi(e);
@@ -1015,6 +1040,10 @@ void gpc_destroy(gpc_ctx* c) {
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
   if (c->ev_up) (void)hipEventDestroy(c->ev_up);
+  for (int g = 0; g <= gpc_ctx::MAXG; ++g) {
+    if (c->ev_l0[g]) (void)hipEventDestroy(c->ev_l0[g]);
+    if (c->ev_l1[g]) (void)hipEventDestroy(c->ev_l1[g]);
+  }
   for (int g = 0; g <= gpc_ctx::MAXG; ++g)
     for (int d = 0; d < gpc_ctx::MAXD; ++d) {
       if (c->ev_fork[g][d]) (void)hipEventDestroy(c->ev_fork[g][d]);
@@ -1237,6 +1266,29 @@ int gpc_last_timing(gpc_ctx* c, double* ms_total, double* ms_factor) {
   if (!c) return -2;
   if (ms_total) *ms_total = c->ms_total;
   if (ms_factor) *ms_factor = c->ms_factor;
+  return 0;
+}
+
+int gpc_set_option(gpc_ctx* c, const char* name, int value) {
+  if (!c || !name) return -2;
+  const std::string n(name);
+  if (n == "groups")
+    c->groups = std::max(1, std::min((int)gpc_ctx::MAXG, value));
+  else if (n == "small_blocks")
+    gpc::g_small_launch_blocks = value;
+  else if (n == "gemm_waves")
+    gpc::g_gemm_waves = value;
+  else if (n == "leaf")
+    gpc::g_leaf_version = value;
+  else
+    FAIL(c, "gpc_set_option: unknown option");
+  return 0;
+}
+
+int gpc_last_lauum_timing(gpc_ctx* c, double* ms, double* flops) {
+  if (!c) return -2;
+  if (ms) *ms = c->ms_lauum;
+  if (flops) *flops = c->flops_lauum;
   return 0;
 }
 

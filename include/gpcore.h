@@ -115,6 +115,16 @@ int gpc_quad(gpc_post* post, const double* mu, const double* sigma, int M, int c
  * gpc_posterior_batch: whole device section, and the part spent in the MFMA GEMM
  * launches + leaf factorizations (the N^3 work).                                    */
 int gpc_last_timing(gpc_ctx* ctx, double* ms_total, double* ms_factor);
+/* The dominant single kernel of the last gpc_nll_batch with gradient: the W^T W ("lauum")
+ * launch of gemm_kernel<T, true, true, ...>.  ms = its duration (hipEvents on the stream it
+ * was launched on; the slowest sample group), flops = its algorithmic flops
+ * (samples in that launch x N^3/3).                                                     */
+int gpc_last_lauum_timing(gpc_ctx* ctx, double* ms, double* flops);
+/* Tuning switches (also settable through the environment at gpc_create: GPC_GROUPS,
+ * GPC_SMALL_BLOCKS, GPC_GEMM_WAVES, GPC_LEAF): "groups" = sample groups on separate HIP
+ * streams (1..8), "small_blocks" = launch size below which 64x64 tiles are used,
+ * "gemm_waves" = 4 | 8, "leaf" = 1 | 2.                                                  */
+int gpc_set_option(gpc_ctx* ctx, const char* name, int value);
 /* fp64/fp32 MFMA issue-rate microbenchmark: achieved TFLOP/s of a register-resident
  * v_mfma_{f64,f32}_16x16x4 loop on all CUs (2 waves per SIMD), the shader cycles one
  * SIMD spends per MFMA, and the clock (GHz) the chip held while running it.  Used to

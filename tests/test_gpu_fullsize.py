@@ -95,3 +95,28 @@ def test_fp32_mode_within_1e3_of_fp64():
         assert (np.abs(d32 - d64) / np.maximum(np.abs(d64), np.abs(d64).max(1, keepdims=True))).max() <= 1e-3
         assert np.abs(mu32 - mu64).max() <= 1e-3 * max(1.0, np.abs(mu64).max())
         assert np.abs(s32 - s64).max() <= 1e-3
+
+
+def test_cfg5_and_cfg4_sizes_size_independent_properties():
+    """N = 8192 (fp64) and N = 16384 (fp32): batch == single, NLL-only == NLL of NLL+grad,
+    directional finite difference of the gradient."""
+    import bench
+
+    for cfg, S, dtype, rtol in [(5, 3, "f64", 1e-6), (4, 1, "f32", 5e-2)]:
+        X, y, hyp = bench.synthetic_problem(cfg, max(S, 2))
+        gp = bench.make_gp(cfg, dtype)
+        gp.update(X_new=X, y_new=y, hyp=hyp[:1], compute_posterior=False)
+        nlz, dnlz = gp.nll_batch(hyp[:S], compute_grad=True)
+        assert np.isfinite(nlz).all() and np.isfinite(dnlz).all()
+        n0, _ = gp.nll_batch(hyp[:S], compute_grad=False)
+        assert np.allclose(n0, nlz, rtol=1e-12 if dtype == "f64" else 1e-5)
+        if S > 1:
+            n1, d1 = gp.nll_batch(hyp[1:2], compute_grad=True)
+            assert n1[0] == nlz[1] and np.array_equal(d1[0], dnlz[1])
+        rng = np.random.default_rng(cfg)
+        v = rng.standard_normal(hyp.shape[1])
+        v /= np.linalg.norm(v)
+        eps = 1e-4 if dtype == "f64" else 1e-2
+        pm, _ = gp.nll_batch(np.stack([hyp[0] + eps * v, hyp[0] - eps * v]))
+        num = (pm[0] - pm[1]) / (2 * eps)
+        assert abs(num - dnlz[0] @ v) < rtol * max(1.0, abs(num))

@@ -19,3 +19,17 @@ if [ "$3" = "pmc" ]; then
   timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE TCC_MISS_sum GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc3 -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc3.log 2>&1; echo "pmc3 exit=$?"
   find $O -name "*counter_collection*" | head
 fi
+# per-grid table of the dominant kernel from the trace (16-sample launches = the isolated measurement)
+python3 - <<PY
+import csv,glob,collections
+f=glob.glob("$O/prof/*/*_kernel_trace.csv")
+if f:
+    g=collections.defaultdict(list)
+    for r in csv.DictReader(open(f[0])):
+        if "gemm_kernel" in r["Kernel_Name"] and "true, true" in r["Kernel_Name"]:
+            g[(r["Kernel_Name"].split("(")[0], int(r["Grid_Size_X"])//int(r["Workgroup_Size_X"]), r["Grid_Size_Y"])].append(float(r["End_Timestamp"])-float(r["Start_Timestamp"]))
+    with open("$O/lauum_by_grid.txt","w") as out:
+        for k,v in sorted(g.items()):
+            line="%s tiles=%d samples=%s launches=%d avg_ms=%.3f min_ms=%.3f"%(k[0],k[1],k[2],len(v),sum(v)/len(v)/1e6,min(v)/1e6)
+            print(line); out.write(line+"\n")
+PY
