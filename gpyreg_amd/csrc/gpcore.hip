@@ -294,6 +294,7 @@ struct Pipe {
     F.sA = F.sW = F.sT = sM;
     F.logdet = d_logdet;
     F.info = d_info;
+    F.nvalid = N;
     F.half_event = half;
     if (c->defer && npad >= 2 * c->defer_min) {
       F.side = c->sst[gidx];
@@ -921,6 +922,7 @@ int debug_factor_impl(gpc_ctx* c, int n, const double* A, double* L, double* W, 
   F.sA = F.sW = F.sT = (long long)msz;
   F.logdet = c->scal.as<double>();
   F.info = reinterpret_cast<int*>(c->scal.as<double>() + 1);
+  F.nvalid = n;
   F.potrf_inv(0, npad, true, true);
   HIPCHK(c, F.err);
   HIPCHK(c, hipGetLastError());

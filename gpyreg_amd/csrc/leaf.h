@@ -179,10 +179,11 @@ constexpr int LDL = TILE + 1;  // LDS stride of the staged L tile
 
 template <typename T, int JB>
 __device__ __forceinline__ void leaf2_steps(T (&M)[8][8], T* __restrict__ pub, T* __restrict__ dbuf,
-                                            T* __restrict__ Ls, int tx, int ty, int& bad) {
+                                            T* __restrict__ Ls, int tx, int ty, int& bad, int nvalid) {
 #pragma clang loop unroll(disable)
   for (int jj = 0; jj < 16; jj += 2) {
     const int j0 = JB * 16 + jj, j1 = j0 + 1;
+    if (j0 >= nvalid) break;  // the rest of the tile is identity padding: nothing to eliminate
     T* C0 = pub + ((jj >> 1) & 1) * 4 * TILE;
     T* C1 = C0 + TILE;
     T* R0 = C1 + TILE;
@@ -303,7 +304,8 @@ __device__ __forceinline__ void leaf2_steps(T (&M)[8][8], T* __restrict__ pub, T
 template <typename T>
 __global__ __launch_bounds__(256) void leaf2_kernel(T* __restrict__ A, long long sA, int lda,
                                                     T* __restrict__ W, long long sW, int ldw, int off,
-                                                    double* __restrict__ logdet, int* __restrict__ info) {
+                                                    double* __restrict__ logdet, int* __restrict__ info,
+                                                    int nvalid) {
   __shared__ T Ls[TILE * LDL];
   __shared__ T pub[8 * TILE];
   __shared__ T dbuf[TILE];
@@ -321,15 +323,28 @@ __global__ __launch_bounds__(256) void leaf2_kernel(T* __restrict__ A, long long
       M[a][b] = (k <= i) ? Ab[(size_t)i * lda + k] : (T)0;
     }
 
+  // columns >= nvalid (rounded up to a pivot pair) are identity padding: their L column is
+  // e_j, their pivot is 1, and the registers already hold the matching rows/columns of W = I
+  const int nelim = min(TILE, (nvalid + 1) & ~1);
+  if (nelim < TILE) {
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const int i = ty + 16 * a, k = tx + 16 * b;
+        if (k >= nelim && k <= i) Ls[i * LDL + k] = (i == k) ? (T)1 : (T)0;
+      }
+    if (t >= nelim && t < TILE) dbuf[t] = (T)1;
+  }
   int bad = 0;
-  leaf2_steps<T, 0>(M, pub, dbuf, Ls, tx, ty, bad);
-  leaf2_steps<T, 1>(M, pub, dbuf, Ls, tx, ty, bad);
-  leaf2_steps<T, 2>(M, pub, dbuf, Ls, tx, ty, bad);
-  leaf2_steps<T, 3>(M, pub, dbuf, Ls, tx, ty, bad);
-  leaf2_steps<T, 4>(M, pub, dbuf, Ls, tx, ty, bad);
-  leaf2_steps<T, 5>(M, pub, dbuf, Ls, tx, ty, bad);
-  leaf2_steps<T, 6>(M, pub, dbuf, Ls, tx, ty, bad);
-  leaf2_steps<T, 7>(M, pub, dbuf, Ls, tx, ty, bad);
+  leaf2_steps<T, 0>(M, pub, dbuf, Ls, tx, ty, bad, nelim);
+  if (nelim > 16) leaf2_steps<T, 1>(M, pub, dbuf, Ls, tx, ty, bad, nelim);
+  if (nelim > 32) leaf2_steps<T, 2>(M, pub, dbuf, Ls, tx, ty, bad, nelim);
+  if (nelim > 48) leaf2_steps<T, 3>(M, pub, dbuf, Ls, tx, ty, bad, nelim);
+  if (nelim > 64) leaf2_steps<T, 4>(M, pub, dbuf, Ls, tx, ty, bad, nelim);
+  if (nelim > 80) leaf2_steps<T, 5>(M, pub, dbuf, Ls, tx, ty, bad, nelim);
+  if (nelim > 96) leaf2_steps<T, 6>(M, pub, dbuf, Ls, tx, ty, bad, nelim);
+  if (nelim > 112) leaf2_steps<T, 7>(M, pub, dbuf, Ls, tx, ty, bad, nelim);
 
 #pragma unroll
   for (int a = 0; a < 8; ++a)

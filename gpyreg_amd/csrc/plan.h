@@ -19,6 +19,8 @@
 #include "gemm.h"
 #include "leaf.h"
 
+#include <algorithm>
+
 namespace gpc {
 
 template <typename T>
@@ -26,6 +28,7 @@ struct Factor {
   hipStream_t st;
   int batch;
   int npad;
+  int nvalid = 1 << 30;  // rows/columns below this index are real data, the rest identity padding
   T* A;
   T* W;
   T* Tm;
@@ -83,7 +86,8 @@ struct Factor {
     if (n == TILE) {
       if (g_leaf_version == 2)
         hipLaunchKernelGGL((leaf2_kernel<T>), dim3(batch), dim3(256), 0, st, blk(A, off, off), sA, npad,
-                           blk(W, off, off), sW, npad, off, logdet, info);
+                           blk(W, off, off), sW, npad, off, logdet, info,
+                           std::max(0, std::min(TILE, nvalid - off)));
       else
         hipLaunchKernelGGL((leaf_kernel<T>), dim3(batch), dim3(256), 0, st, blk(A, off, off), sA, npad,
                            blk(W, off, off), sW, npad, off, logdet, info);
