@@ -48,6 +48,7 @@ SIGNATURES = {
     "gpc_post_fetch": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
     "gpc_post_free": (C.c_int, [_vp]),
     "gpc_predict": (C.c_int, [_vp, _dp, C.c_int, _dp, _dp]),
+    "gpc_post_append": (C.c_int, [_vp, _dp, _dp, C.c_double, _ip]),
     "gpc_predict_full": (C.c_int, [_vp, _dp, C.c_int, _dp, _dp]),
     "gpc_quad": (C.c_int, [_vp, _dp, _dp, C.c_int, C.c_int, _dp, _dp]),
     "gpc_last_timing": (C.c_int, [_vp, _dp, _dp]),
@@ -270,6 +271,18 @@ class PostHandle:
         rc = self.ctx._lib.gpc_predict(self._h, _ptr(xs), M, _ptr(fmu), _ptr(fs2))
         self.ctx._check(rc, "gpc_predict")
         return fmu, fs2
+
+    def append(self, m_star, sn2_star, y_new):
+        """Rank-one append of the point already added to the context's data; True if applied."""
+        m_star, sn2_star = _f64(m_star).ravel(), _f64(sn2_star).ravel()
+        ok = np.zeros(self.S, dtype=np.int32)
+        rc = self.ctx._lib.gpc_post_append(self._h, _ptr(m_star), _ptr(sn2_star), float(y_new),
+                                           ok.ctypes.data_as(_ip))
+        self.ctx._check(rc, "gpc_post_append")
+        applied = bool(ok.all())
+        if applied:
+            self.N += 1
+        return applied
 
     def predict_full(self, x_star):
         xs = _f64(x_star)

@@ -229,6 +229,49 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(T* out, int iters, long 
   out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// ---- rank-one append of a training point to resident posteriors (gaussian_process.py:750-844) ----
+// dst[b] ((npn x npn), identity-padded) <- src[b] (np x np top-left block).  grid = (npn/64, npn/4, batch)
+template <typename T>
+__global__ void grow_copy_kernel(const T* __restrict__ src, int np, T* __restrict__ dst, int npn) {
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  const int i = blockIdx.y * 4 + threadIdx.y;
+  if (i >= npn || j >= npn) return;
+  const size_t b = blockIdx.z;
+  T v = (i == j) ? (T)1 : (T)0;
+  if (i < np && j < np) v = src[b * (size_t)np * np + (size_t)i * np + j];
+  dst[b * (size_t)npn * npn + (size_t)i * npn + j] = v;
+}
+
+// Row n of the lower factor and of its inverse, and the updated alpha, for every sample b:
+//   Lo[n][k] = l[k] * cl[b] (k < n),  Lo[n][n] = dl[b]
+//   W [n][k] = au[k] * cw[b] (k < n), W [n][n] = 1 / dl[b]
+//   alpha[k] += ca[b] * au[k] * cau[b] (k < n),  alpha[n] = -ca[b]
+// l = W Ks, au = W^T l (un-normalised); the host derived the per-sample coefficients.
+// coef[b] = {cl, dl, cw, ca, cau}.   grid = (npad/256, batch)
+template <typename T>
+__global__ __launch_bounds__(256) void append_row_kernel(T* __restrict__ A_all, T* __restrict__ W_all, long long sM,
+                                                         int ld, int n, const double* __restrict__ l_all,
+                                                         const double* __restrict__ au_all, int npad,
+                                                         const double* __restrict__ coef,
+                                                         double* __restrict__ alpha_all) {
+  const int b = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+  if (k > n) return;
+  const double* cf = coef + (size_t)b * 5;
+  T* Arow = A_all + (size_t)b * sM + (size_t)n * ld;
+  T* Wrow = W_all + (size_t)b * sM + (size_t)n * ld;
+  double* alpha = alpha_all + (size_t)b * npad;
+  if (k < n) {
+    const double lv = l_all[(size_t)b * npad + k], av = au_all[(size_t)b * npad + k];
+    Arow[k] = (T)(lv * cf[0]);
+    Wrow[k] = (T)(av * cf[2]);
+    alpha[k] += cf[3] * av * cf[4];
+  } else {
+    Arow[n] = (T)cf[1];
+    Wrow[n] = (T)(1.0 / cf[1]);
+    alpha[n] = -cf[3];
+  }
+}
+
 // independent-chain VALU FMA loop (what the non-MFMA kernels are bounded by)
 template <typename T>
 __global__ __launch_bounds__(256) void valu_peak_kernel(T* out, int iters, long long* clk) {

@@ -339,6 +339,30 @@ __global__ void cross_kernel(CovDesc cd, const double* __restrict__ Xs_all,
 }
 
 // ---------------------------------------------------------------------------------
+// ks[b][i] = k(x_i, x_n) for i < n, 0 for i >= n, from the scaled inputs Xs[b] (row n = the
+// appended point).  grid = (npad/256, batch)
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cross_vec_kernel(CovDesc cd, const double* __restrict__ Xs_all,
+                                                        const double* __restrict__ sp_all, int n, int npad,
+                                                        double* __restrict__ ks_all) {
+  const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= npad) return;
+  double v = 0.0;
+  if (i < n) {
+    const double* xi = Xs_all + ((size_t)b * npad + i) * cd.D;
+    const double* xn = Xs_all + ((size_t)b * npad + n) * cd.D;
+    double r2 = 0.0;
+    for (int h = 0; h < cd.D; ++h) {
+      const double d = xi[h] - xn[h];
+      r2 += d * d;
+    }
+    const double* sp = sp_all + (size_t)b * SP_STRIDE;
+    v = pair_eval(cd.kind, cd.degree, r2, sp[SP_SF2], sp[SP_RQA]).K;
+  }
+  ks_all[(size_t)b * npad + i] = v;
+}
+
+// ---------------------------------------------------------------------------------
 // Bayesian-quadrature kernel means (gaussian_process.py:1908-1921), SE kernel only:
 //   z[b][n][j] = exp( ln sf2 + sum ln ell - sum_l ln tau_jl - 1/2 sum_l ((mu_jl - X_nl)/tau_jl)^2 )
 //   tau_jl = sqrt(sigma_jl^2 + ell_l^2),  ell_l = dv[b][l] (the SE scaling divides X by ell)

@@ -954,6 +954,115 @@ int debug_factor_impl(gpc_ctx* c, int n, const double* A, double* L, double* W, 
 }
 }  // namespace
 
+namespace {
+// rank-one append, all samples L_chol with scalar noise (checked by the caller)
+template <typename T>
+int append_impl(gpc_post* po, const double* m_star, const double* sn2_star, double y_new, int* ok) {
+  gpc_ctx* c = po->ctx;
+  const int S = po->S, D = po->D, n = po->N;  // the new point is row n of the context's X
+  hipStream_t st = c->st;
+  if (c->N != n + 1) FAIL(c, "gpc_post_append: call gpc_set_data with the extended X, y first");
+  // grow the padded storage by one tile when the new row does not fit
+  if (n + 1 > po->npad) {
+    const int np = po->npad, npn = np + TILE;
+    DevBuf nA, nW, nal;
+    HIPCHK(c, nA.ensure((size_t)S * npn * npn * sizeof(T)));
+    HIPCHK(c, nW.ensure((size_t)S * npn * npn * sizeof(T)));
+    HIPCHK(c, nal.ensure((size_t)S * npn * sizeof(double)));
+    dim3 g(npn / 64, npn / 4, S), blk(64, 4);
+    hipLaunchKernelGGL((grow_copy_kernel<T>), g, blk, 0, st, (const T*)po->A.as<T>(), np, nA.as<T>(), npn);
+    hipLaunchKernelGGL((grow_copy_kernel<T>), g, blk, 0, st, (const T*)po->W.as<T>(), np, nW.as<T>(), npn);
+    HIPCHK(c, hipMemsetAsync(nal.p, 0, (size_t)S * npn * sizeof(double), st));
+    HIPCHK(c, hipMemcpy2DAsync(nal.p, (size_t)npn * 8, po->alpha.p, (size_t)np * 8, (size_t)np * 8, S,
+                               hipMemcpyDeviceToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    po->A.release();
+    po->W.release();
+    po->alpha.release();
+    po->A = nA;
+    po->W = nW;
+    po->alpha = nal;
+    po->npad = npn;
+  }
+  const int npad = po->npad;
+  const long long sM = (long long)npad * npad;
+  const size_t vb = (size_t)npad * 8;
+  HIPCHK(c, c->xs.ensure((size_t)S * npad * D * 8));
+  HIPCHK(c, c->spb.ensure((size_t)S * SP_STRIDE * 8));
+  HIPCHK(c, c->mulb.ensure((size_t)S * D * 8));
+  HIPCHK(c, c->divb.ensure((size_t)S * D * 8));
+  HIPCHK(c, c->rvec.ensure(S * vb));
+  HIPCHK(c, c->zvec.ensure(S * vb));
+  HIPCHK(c, c->avec.ensure(S * vb));
+  HIPCHK(c, c->tpart.ensure((size_t)S * (npad / TRC + 1) * vb));
+  HIPCHK(c, c->scal.ensure((size_t)S * 8 * 8));
+  HIPCHK(c, hipMemcpyAsync(c->spb.p, po->sp.data(), (size_t)S * SP_STRIDE * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(c->mulb.p, po->mul.data(), (size_t)S * D * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(c->divb.p, po->dv.data(), (size_t)S * D * 8, hipMemcpyHostToDevice, st));
+  {
+    const long long tot = (long long)npad * D;
+    hipLaunchKernelGGL(scale_x_kernel, dim3((unsigned)((tot + 255) / 256), S), dim3(256), 0, st,
+                       c->dX.as<double>(), n + 1, npad, D, c->mulb.as<double>(), c->divb.as<double>(),
+                       c->xs.as<double>());
+  }
+  double* ks = c->rvec.as<double>();  // Ks
+  double* lv = c->zvec.as<double>();  // l = W Ks
+  double* au = c->avec.as<double>();  // W^T l
+  double* d_ll = c->scal.as<double>();
+  double* d_ka = d_ll + S;
+  hipLaunchKernelGGL(cross_vec_kernel, dim3((npad + 255) / 256, S), dim3(256), 0, st, po->cd,
+                     c->xs.as<double>(), c->spb.as<double>(), n, npad, ks);
+  hipLaunchKernelGGL((trmv_kernel<T>), dim3(npad / 4, S), dim3(256), 0, st, (const T*)po->W.as<T>(), sM, npad,
+                     (const double*)ks, npad, lv, 0);
+  hipLaunchKernelGGL(dot_kernel, dim3(1, S), dim3(256), 0, st, (const double*)lv, (const double*)lv, n, npad, d_ll);
+  hipLaunchKernelGGL(dot_kernel, dim3(1, S), dim3(256), 0, st, (const double*)ks,
+                     (const double*)po->alpha.as<double>(), n, npad, d_ka);
+  // the padding rows of W are identity rows: l[i >= n] = Ks[i] = 0, harmless in W^T l
+  double* tpart = c->tpart.as<double>();
+  hipLaunchKernelGGL((trmv_t_part_kernel<T>), dim3(npad / 64, npad / TRC, S), dim3(256), 0, st,
+                     (const T*)po->W.as<T>(), sM, npad, (const double*)lv, npad, tpart);
+  hipLaunchKernelGGL(trmv_t_sum_kernel, dim3(npad / 128, S), dim3(128), 0, st, (const double*)tpart, npad,
+                     (const double*)nullptr, 0, 0, au);
+  HIPCHK(c, hipGetLastError());
+  std::vector<double> ll(S), ka(S), coef((size_t)S * 5);
+  HIPCHK(c, hipMemcpyAsync(ll.data(), d_ll, S * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(ka.data(), d_ka, S * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  bool all_ok = true;
+  for (int s = 0; s < S; ++s) {
+    const double sf2 = po->sp[(size_t)s * SP_STRIDE + SP_SF2];
+    const double sl = po->sp[(size_t)s * SP_STRIDE + SP_SL];  // = sn2 * sn2_mult of the fitted noise
+    const double sn2_eff = sn2_star[s] * po->mult[s];
+    // gaussian_process.py:784-788 (K = kss = sf2)
+    const double sqrt_arg = sn2_eff * sn2_eff + sf2 * sn2_eff - ll[s];
+    ok[s] = (sqrt_arg > 0.0 && std::abs(sn2_eff - sl) <= 1e-12 * sl) ? 1 : 0;
+    if (!ok[s]) {
+      all_ok = false;
+      continue;
+    }
+    const double dl = std::sqrt(sqrt_arg) / sn2_eff;       // new diagonal entry of the factor (:814)
+    const double v_star = sf2 - ll[s] / sl + sn2_eff;      // predictive variance incl. noise (:756)
+    const double mu_star = m_star[s] + ka[s];              // predictive mean at the new point
+    coef[(size_t)s * 5 + 0] = 1.0 / sn2_eff;               // Lo[n][:n] = l / sn2_eff  (:811)
+    coef[(size_t)s * 5 + 1] = dl;
+    coef[(size_t)s * 5 + 2] = -1.0 / (dl * sn2_eff);       // W[n][:n] = -(l/sn2_eff)^T W / dl
+    coef[(size_t)s * 5 + 3] = (mu_star - y_new) / v_star;  // alpha update weight (:842)
+    coef[(size_t)s * 5 + 4] = 1.0 / sn2_eff;               // alpha_update = W^T l / sn2_eff (:800-808)
+  }
+  if (!all_ok) return 0;  // nothing was modified; the caller recomputes
+  double* d_coef = c->scal.as<double>() + 2 * S;
+  HIPCHK(c, hipMemcpyAsync(d_coef, coef.data(), coef.size() * 8, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL((append_row_kernel<T>), dim3((n + 256) / 256, S), dim3(256), 0, st, po->A.as<T>(),
+                     po->W.as<T>(), sM, npad, n, (const double*)lv, (const double*)au, npad,
+                     (const double*)d_coef, po->alpha.as<double>());
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(st));
+  po->N = n + 1;
+  return 0;
+}
+}  // namespace
+
+
 // =====================================================================================
 // C ABI
 // =====================================================================================
@@ -1217,6 +1326,19 @@ int gpc_post_free(gpc_post* po) {
   po->alpha.release();
   delete po;
   return 0;
+}
+
+int gpc_post_append(gpc_post* po, const double* m_star, const double* sn2_star, double y_new, int* ok) {
+  if (!po) return -2;
+  gpc_ctx* c = po->ctx;
+  if (!m_star || !sn2_star || !ok) FAIL(c, "gpc_post_append: null argument");
+  for (int s = 0; s < po->S; ++s) {
+    ok[s] = 0;
+    if (po->info[s] != 0 || !po->lchol[s]) return 0;  // not applicable: the caller recomputes
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  return po->dtype == GPC_F64 ? append_impl<double>(po, m_star, sn2_star, y_new, ok)
+                              : append_impl<float>(po, m_star, sn2_star, y_new, ok);
 }
 
 int gpc_predict(gpc_post* po, const double* xstar, int M, double* fmu, double* fs2) {

@@ -650,9 +650,11 @@ class GP:
     # ------------------------------------------------------------------ data / posterior
     def update(self, X_new=None, y_new=None, s2_new=None, hyp=None, compute_posterior: bool = True):
         """Add data and/or replace hyperparameters, then rebuild every posterior
-        (reference :691-884).  The reference's rank-one shortcut for a single new
-        point (:750-844) is replaced by the same full recompute it falls back to:
-        on the device an N^3/3 refactorization is cheaper than shipping L back."""
+        (reference :691-884).  A single new observation (no ``s2``, no new ``hyp``, existing
+        posteriors in the high-noise parametrisation with scalar noise) takes the reference's
+        rank-one path (:750-844) on the device: the factor, its inverse and alpha get a new
+        last row in O(N^2).  Anything else -- and a numerically unstable append
+        (``sqrt_arg <= 0``, :789-798) -- is the full recompute loop (:870-884)."""
         X_new, y_new, s2_new = self._convert_shapes(X_new, y_new, s2_new)
         if X_new is not None:
             X_new = X_new.copy()
@@ -663,6 +665,25 @@ class GP:
         if hyp is not None:
             hyp = np.atleast_2d(np.asarray(hyp, dtype=float)).copy()
 
+        rank_one = (X_new is not None and y_new is not None and compute_posterior
+                    and self.X is not None and self.y is not None and X_new.shape[0] == 1
+                    and y_new.shape[0] == 1 and s2_new is None and hyp is None
+                    and self.s2 is None and self._post_handle is not None)
+        append_args = None
+        if rank_one:
+            cov_N, noise_N, mean_N = self._counts()
+            m_star, sn2_star = [], []
+            for p in self.posteriors:
+                h = p.hyp
+                sn2 = self.noise.compute(h[cov_N:cov_N + noise_N], X_new, y_new, 0)
+                if not np.isscalar(sn2):
+                    rank_one = False  # per-point noise: the append formulas do not apply
+                    break
+                sn2_star.append(float(sn2))
+                m_star.append(float(np.ravel(self.mean.compute(
+                    h[cov_N + noise_N:cov_N + noise_N + mean_N], X_new))[0]))
+            append_args = (m_star, sn2_star, float(y_new[0, 0]))
+
         if X_new is not None:
             self.X = X_new if self.X is None else np.concatenate((self.X, X_new))
         if y_new is not None:
@@ -671,6 +692,14 @@ class GP:
             self.s2 = s2_new if self.s2 is None else np.concatenate((self.s2, s2_new))
         if X_new is not None or y_new is not None:
             self._token = None  # device copy of X, y is stale
+
+        if rank_one:
+            self._ctx()  # uploads the extended X, y
+            if self._post_handle.append(*append_args):
+                for p in self.posteriors:  # cached host copies are stale; refetch lazily
+                    p._alpha = p._sW = p._L = None
+                    p._have = {"alpha": False, "sW": False, "L": False}
+                return
 
         if hyp is None:
             hyp = self.get_hyperparameters(as_array=True)

@@ -97,6 +97,17 @@ int gpc_post_free(gpc_post* post);
  *   fs2[j*S + s]  = kss - colsum(V*V)   or   kss + colsum(Ks * (L Ks))   (unclamped) */
 int gpc_predict(gpc_post* post, const double* xstar, int M, double* fmu, double* fs2);
 
+/* ---- rank-one append of ONE training point to resident posteriors (GP.update fast path,
+ *      gaussian_process.py:750-844, high-noise parametrisation with scalar noise) --------------
+ * Call gpc_set_data with the extended X (N+1 rows; the new point last) and y first.
+ *   m_star[s]   mean function of sample s at the new point
+ *   sn2_star[s] noise variance of sample s at the new point (noise.compute(hyp, x_new, y_new, 0))
+ * Per sample: l = W Ks, sqrt_arg = sn2_eff^2 + kss sn2_eff - l.l (:784-788); the factor, its
+ * inverse and alpha get their new last row in O(N^2).  ok[s] = 1 if appended.  If ANY sample is
+ * not eligible (low-noise parametrisation, failed factorization) or has sqrt_arg <= 0, nothing is
+ * modified and every ok[s] = 0: the caller recomputes (the reference's own fallback, :864-867). */
+int gpc_post_append(gpc_post* post, const double* m_star, const double* sn2_star, double y_new, int* ok);
+
 /* ---- GP.predict_full (gaussian_process.py:1603-1650) -------------------------------------
  * fmu[j*S + s] = Ks^T alpha;  cov[s] (M x M, row-major) = K** - V^T V  or  K** + Ks^T (L Ks)
  * (the caller symmetrises and adds noise, :1647-1659).                                    */
