@@ -11,8 +11,10 @@
 #include "../../include/gpcore.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 
 #include "blas1.h"
@@ -51,6 +53,85 @@ struct DevBuf {
   }
 };
 
+// Page-locked host staging for transfers between the caller's (pageable) arrays and HBM.
+// Copies straight from/to pageable memory go through the runtime's pin-on-demand path, measured
+// at ~20 ms of fixed host time for the first multi-MB copy of a call (S=1024, N=500: 30 ms per
+// batched evaluation, 6 ms with staging); staging through long-lived pinned blocks costs a host
+// memcpy (~30 GB/s) and makes the copy truly asynchronous.  Lifetime: begin() at the top of an
+// entry point (the stream is idle there: every entry point ends with a sync), finish() after
+// the final sync delivers the downloads.
+struct PinBuf {
+  struct Blk {
+    char* p;
+    size_t bytes, used;
+  };
+  struct Pending {
+    void* dst;
+    const void* src;
+    size_t n;
+  };
+  std::vector<Blk> blks;
+  std::vector<Pending> pend;
+  static constexpr size_t kMin = 32u << 10;    // smaller copies: the runtime's own staging is fine
+  static constexpr size_t kMax = 512ull << 20; // larger ones amortise the pin-on-demand cost themselves
+
+  void begin() {
+    pend.clear();
+    if (blks.size() > 1) {  // the previous call outgrew its block: one block of the total next time
+      size_t tot = 0;
+      for (Blk& b : blks) {
+        tot += b.bytes;
+        (void)hipHostFree(b.p);
+      }
+      blks.clear();
+      (void)alloc(tot);
+    }
+    for (Blk& b : blks) b.used = 0;
+  }
+  void* alloc(size_t n) {
+    n = (n + 255) & ~(size_t)255;
+    if (!blks.empty() && blks.back().used + n <= blks.back().bytes) {
+      void* r = blks.back().p + blks.back().used;
+      blks.back().used += n;
+      return r;
+    }
+    Blk b{nullptr, std::max(n + n / 2, (size_t)4 << 20), 0};
+    if (hipHostMalloc(reinterpret_cast<void**>(&b.p), b.bytes, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    b.used = n;
+    blks.push_back(b);
+    return b.p;
+  }
+  hipError_t up(void* dst, const void* src, size_t n, hipStream_t st) {
+    if (n >= kMin && n <= kMax)
+      if (void* h = alloc(n)) {
+        memcpy(h, src, n);
+        src = h;
+      }
+    return hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, st);
+  }
+  // the data lands in dst at finish(), which the caller runs after synchronising the stream
+  hipError_t down(void* dst, const void* src, size_t n, hipStream_t st) {
+    if (n >= kMin && n <= kMax)
+      if (void* h = alloc(n)) {
+        pend.push_back({dst, h, n});
+        dst = h;
+      }
+    return hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, st);
+  }
+  void finish() {
+    for (Pending& q : pend) memcpy(q.dst, q.src, q.n);
+    pend.clear();
+  }
+  void release() {
+    for (Blk& b : blks) (void)hipHostFree(b.p);
+    blks.clear();
+    pend.clear();
+  }
+};
+
 }  // namespace
 
 struct gpc_ctx {
@@ -86,6 +167,38 @@ struct gpc_ctx {
   DevBuf dmb, dsn2b, mg, ng;     // mean / noise gradient inputs and outputs
   DevBuf ks, vb, kss, xss, pout; // predict / predict_full / quad
   DevBuf dbg1, dbg2, dbg3;       // debug hooks / fetch staging
+  PinBuf pin;                    // pinned staging for host<->device transfers (see PinBuf)
+  // Freed posterior storage, kept for the next gpc_posterior_batch: hipMalloc/hipFree of the
+  // multi-GB S x npad^2 factors cost more than computing them (update() in a fit / active-learning
+  // loop creates a new posterior set and drops the previous one every iteration).
+  std::vector<DevBuf> pool;
+  DevBuf pool_take(size_t need) {
+    int best = -1;
+    for (int i = 0; i < (int)pool.size(); ++i)
+      if (pool[i].bytes >= need && pool[i].bytes <= need + need / 2 &&
+          (best < 0 || pool[i].bytes < pool[best].bytes))
+        best = i;
+    DevBuf r;
+    if (best >= 0) {
+      r = pool[best];
+      pool.erase(pool.begin() + best);
+    }
+    return r;
+  }
+  void pool_give(DevBuf& b) {
+    if (!b.p) return;
+    pool.push_back(b);
+    b.p = nullptr;
+    b.bytes = 0;
+    while (pool.size() > 6) {  // two generations of (A, W, alpha)
+      pool.front().release();
+      pool.erase(pool.begin());
+    }
+  }
+  void pool_drain() {
+    for (DevBuf& b : pool) b.release();
+    pool.clear();
+  }
   double ms_total = 0, ms_factor = 0;
   double last_flops = 0;
 };
@@ -234,6 +347,22 @@ struct Batch {
 
 
 enum Mode { MODE_NLL = 0, MODE_GRAD = 1, MODE_POST = 2 };
+
+// GPC_HOSTTIME=1: host wall-clock of the phases of a call, to stderr (diagnostics only)
+struct HostClock {
+  bool on;
+  const char* tag;
+  std::chrono::steady_clock::time_point t;
+  explicit HostClock(const char* tg) : on(getenv("GPC_HOSTTIME") != nullptr), tag(tg) {
+    if (on) t = std::chrono::steady_clock::now();
+  }
+  void lap(const char* what) {
+    if (!on) return;
+    auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "[gpc %s] %-10s %8.3f ms\n", tag, what, std::chrono::duration<double, std::milli>(n - t).count());
+    t = n;
+  }
+};
 
 template <typename T>
 struct Pipe {
@@ -406,21 +535,22 @@ struct Pipe {
       }
     }
 
+    HostClock hc("run");
+    c->pin.begin();
+    auto up = [&](void* dst, const void* src, size_t n) { return c->pin.up(dst, src, n, st); };
     HIPCHK(c, hipEventRecord(c->ev[0], st));
-    HIPCHK(c, hipMemcpyAsync(c->spb.p, &b.sp[(size_t)s0 * SP_STRIDE], (size_t)cnt * SP_STRIDE * 8,
-                             hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->mulb.p, &b.mul[(size_t)s0 * D], (size_t)cnt * D * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->divb.p, &b.dv[(size_t)s0 * D], (size_t)cnt * D * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->dvec.p, &b.dvec[(size_t)s0 * npad], cnt * vb, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->rvec.p, &b.r[(size_t)s0 * npad], cnt * vb, hipMemcpyHostToDevice, st));
+    HIPCHK(c, up(c->spb.p, &b.sp[(size_t)s0 * SP_STRIDE], (size_t)cnt * SP_STRIDE * 8));
+    HIPCHK(c, up(c->mulb.p, &b.mul[(size_t)s0 * D], (size_t)cnt * D * 8));
+    HIPCHK(c, up(c->divb.p, &b.dv[(size_t)s0 * D], (size_t)cnt * D * 8));
+    HIPCHK(c, up(c->dvec.p, &b.dvec[(size_t)s0 * npad], cnt * vb));
+    HIPCHK(c, up(c->rvec.p, &b.r[(size_t)s0 * npad], cnt * vb));
     HIPCHK(c, hipMemsetAsync(c->scal.p, 0, (size_t)cnt * (2 * sizeof(double) + sizeof(int)), st));
     if (mode == MODE_GRAD && mean_N > 0)
-      HIPCHK(c, hipMemcpyAsync(c->dmb.p, dm + (size_t)s0 * N * mean_N, (size_t)cnt * N * mean_N * 8,
-                               hipMemcpyHostToDevice, st));
+      HIPCHK(c, up(c->dmb.p, dm + (size_t)s0 * N * mean_N, (size_t)cnt * N * mean_N * 8));
     if (mode == MODE_GRAD && noise_N > 0 && b.vec_noise)
-      HIPCHK(c, hipMemcpyAsync(c->dsn2b.p, dsn2 + (size_t)s0 * N * noise_N, (size_t)cnt * N * noise_N * 8,
-                               hipMemcpyHostToDevice, st));
+      HIPCHK(c, up(c->dsn2b.p, dsn2 + (size_t)s0 * N * noise_N, (size_t)cnt * N * noise_N * 8));
 
+    hc.lap("h2d");
     int groups = c->groups;
     if (cnt < 2 * groups || npad < 1024) groups = 1;
     if (groups == 1) {
@@ -443,6 +573,7 @@ struct Pipe {
     }
     HIPCHK(c, hipEventRecord(c->ev[3], st));
 
+    hc.lap("launch");
     // results back
     std::vector<int> hinfo(cnt);
     HIPCHK(c, hipMemcpyAsync(&logdet[s0], d_logdet, cnt * 8, hipMemcpyDeviceToHost, st));
@@ -458,6 +589,7 @@ struct Pipe {
                                  hipMemcpyDeviceToHost, st));
     }
     HIPCHK(c, hipStreamSynchronize(st));
+    hc.lap("d2h+sync");
     for (int i = 0; i < cnt; ++i) b.info[s0 + i] = (gpc::g_gemm_flags & 6) ? 0 : hinfo[i];  // timing-only modes
     float t03 = 0, t12 = 0;
     (void)hipEventElapsedTime(&t03, c->ev[0], c->ev[3]);
@@ -508,9 +640,16 @@ int nll_impl(gpc_ctx* c, Batch& b, int want_grad, const double* dm, int mean_N, 
              int noise_N, double* nlz, double* dnlz, double* sn2_mult, int* L_chol, int* info) {
   const int S = b.S, npad = b.npad, N = b.N;
   const size_t per = 3ull * npad * npad * sizeof(T);
-  size_t budget = free_device_bytes() + (getenv("GPC_MEM_BUDGET_MB") ? 0 : c->mA.bytes + c->mW.bytes + c->mT.bytes);
-  budget = (size_t)(budget * 0.8);
-  int chunk = (int)std::max<size_t>(1, std::min<size_t>(S, budget / per));
+  int chunk = S;
+  const bool forced = getenv("GPC_MEM_BUDGET_MB") != nullptr;
+  if (forced || (size_t)S * per > c->mA.bytes + c->mW.bytes + c->mT.bytes) {
+    // the workspace must grow: size the chunk to what is free (hipMemGetInfo is slow, so it is
+    // only consulted here)
+    c->pool_drain();
+    size_t budget = free_device_bytes() + (forced ? 0 : c->mA.bytes + c->mW.bytes + c->mT.bytes);
+    budget = (size_t)(budget * 0.8);
+    chunk = (int)std::max<size_t>(1, std::min<size_t>(S, budget / per));
+  }
   HIPCHK(c, c->mA.ensure((size_t)chunk * npad * npad * sizeof(T)));
   HIPCHK(c, c->mW.ensure((size_t)chunk * npad * npad * sizeof(T)));
   HIPCHK(c, c->mT.ensure((size_t)chunk * npad * npad * sizeof(T)));
@@ -602,12 +741,23 @@ template <typename T>
 int post_impl(gpc_ctx* c, Batch& b, gpc_post* po, double* sn2_mult, int* L_chol, int* info) {
   const int S = b.S, npad = b.npad;
   const size_t msz = (size_t)npad * npad * sizeof(T);
+  HostClock hc("post");
+  po->A = c->pool_take(S * msz);
+  po->W = c->pool_take(S * msz);
+  po->alpha = c->pool_take((size_t)S * npad * sizeof(double));
+  if (!po->A.p || !po->W.p) c->pool_drain();  // nothing reusable: give the memory back before growing
   HIPCHK(c, po->A.ensure(S * msz));
   HIPCHK(c, po->W.ensure(S * msz));
   HIPCHK(c, po->alpha.ensure((size_t)S * npad * sizeof(double)));
-  size_t budget = (size_t)((free_device_bytes() + (getenv("GPC_MEM_BUDGET_MB") ? 0 : c->mT.bytes)) * 0.8);
-  int chunk = (int)std::max<size_t>(1, std::min<size_t>(S, budget / msz));
+  hc.lap("alloc A,W");
+  int chunk = S;
+  if (getenv("GPC_MEM_BUDGET_MB") || (size_t)S * msz > c->mT.bytes) {
+    c->pool_drain();
+    size_t budget = (size_t)((free_device_bytes() + (getenv("GPC_MEM_BUDGET_MB") ? 0 : c->mT.bytes)) * 0.8);
+    chunk = (int)std::max<size_t>(1, std::min<size_t>(S, budget / msz));
+  }
   HIPCHK(c, c->mT.ensure((size_t)chunk * msz));
+  hc.lap("alloc T");
 
   Pipe<T> p;
   p.c = c;
@@ -662,6 +812,7 @@ int post_impl(gpc_ctx* c, Batch& b, gpc_post* po, double* sn2_mult, int* L_chol,
       }
     HIPCHK(c, hipStreamSynchronize(c->st));
   }
+  hc.lap("device");
   po->sp = b.sp;
   po->mul = b.mul;
   po->dv = b.dv;
@@ -697,9 +848,15 @@ int rhs_products(gpc_post* po, int mode, const double* xa, const double* xb, int
   const long long sKs = (long long)npad * mpad;
   const long long sKss = (long long)mpad * mpad;
   const size_t per = (2ull * npad * mpad + (full ? (size_t)mpad * mpad : 0)) * sizeof(T);
-  size_t budget = (size_t)((free_device_bytes() +
-                            (getenv("GPC_MEM_BUDGET_MB") ? 0 : c->ks.bytes + c->vb.bytes + c->kss.bytes)) * 0.8);
-  int chunk = (int)std::max<size_t>(1, std::min<size_t>(S, budget / per));
+  int chunk = S;
+  if (getenv("GPC_MEM_BUDGET_MB") || (size_t)S * per > c->ks.bytes + c->vb.bytes + c->kss.bytes ||
+      (size_t)S * sKs * sizeof(T) > std::min(c->ks.bytes, c->vb.bytes) ||
+      (full && (size_t)S * sKss * sizeof(T) > c->kss.bytes)) {
+    c->pool_drain();
+    size_t budget = (size_t)((free_device_bytes() +
+                              (getenv("GPC_MEM_BUDGET_MB") ? 0 : c->ks.bytes + c->vb.bytes + c->kss.bytes)) * 0.8);
+    chunk = (int)std::max<size_t>(1, std::min<size_t>(S, budget / per));
+  }
   HIPCHK(c, c->ks.ensure((size_t)chunk * sKs * sizeof(T)));
   HIPCHK(c, c->vb.ensure((size_t)chunk * sKs * sizeof(T)));
   if (full) HIPCHK(c, c->kss.ensure((size_t)chunk * sKss * sizeof(T)));
@@ -711,9 +868,24 @@ int rhs_products(gpc_post* po, int mode, const double* xa, const double* xb, int
   HIPCHK(c, c->pout.ensure((size_t)chunk * mpad * 2 * 8));
   double* d_xa = c->xss.as<double>() + (size_t)chunk * mpad * D;
   double* d_xb = d_xa + (size_t)M * D;
-  HIPCHK(c, hipMemcpyAsync(d_xa, xa, (size_t)M * D * 8, hipMemcpyHostToDevice, st));
-  if (xb) HIPCHK(c, hipMemcpyAsync(d_xb, xb, (size_t)M * D * 8, hipMemcpyHostToDevice, st));
-  std::vector<double> hmu((size_t)chunk * mpad), hv((size_t)chunk * mpad);
+  c->pin.begin();
+  HIPCHK(c, c->pin.up(d_xa, xa, (size_t)M * D * 8, st));
+  if (xb) HIPCHK(c, c->pin.up(d_xb, xb, (size_t)M * D * 8, st));
+  // landing buffers of the per-chunk results (pinned when available)
+  std::vector<double> hmu_v, hv_v;
+  double* hmu = static_cast<double*>(c->pin.alloc((size_t)chunk * mpad * 8));
+  double* hv = static_cast<double*>(c->pin.alloc((size_t)chunk * mpad * 8));
+  if (!hmu) {
+    hmu_v.resize((size_t)chunk * mpad);
+    hmu = hmu_v.data();
+  }
+  if (!hv) {
+    hv_v.resize((size_t)chunk * mpad);
+    hv = hv_v.data();
+  }
+  double* hfull = nullptr;
+  if (full && (size_t)M * M * 8 >= PinBuf::kMin && (size_t)M * M * 8 <= PinBuf::kMax)
+    hfull = static_cast<double*>(c->pin.alloc((size_t)M * M * 8));
 
   for (int s0 = 0; s0 < S; s0 += chunk) {
     const int cnt = std::min(chunk, S - s0);
@@ -797,17 +969,18 @@ int rhs_products(gpc_post* po, int mode, const double* xa, const double* xb, int
       a = e;
     }
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(hmu.data(), d_mu, (size_t)cnt * mpad * 8, hipMemcpyDeviceToHost, st));
-    if (want_quad) HIPCHK(c, hipMemcpyAsync(hv.data(), d_v, (size_t)cnt * mpad * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(hmu, d_mu, (size_t)cnt * mpad * 8, hipMemcpyDeviceToHost, st));
+    if (want_quad) HIPCHK(c, hipMemcpyAsync(hv, d_v, (size_t)cnt * mpad * 8, hipMemcpyDeviceToHost, st));
     if (full) {
       HIPCHK(c, c->dbg3.ensure((size_t)M * M * 8));
       for (int i = 0; i < cnt; ++i) {
         dim3 gn((M + 63) / 64, (M + 3) / 4), blk(64, 4);
         hipLaunchKernelGGL((extract_kernel<T>), gn, blk, 0, st, (const T*)(c->kss.as<T>() + (size_t)i * sKss),
                            mpad, M, 2, c->dbg3.as<double>());
-        HIPCHK(c, hipMemcpyAsync(full + (size_t)(s0 + i) * M * M, c->dbg3.p, (size_t)M * M * 8,
-                                 hipMemcpyDeviceToHost, st));
+        double* dst = full + (size_t)(s0 + i) * M * M;
+        HIPCHK(c, hipMemcpyAsync(hfull ? hfull : dst, c->dbg3.p, (size_t)M * M * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
+        if (hfull) memcpy(dst, hfull, (size_t)M * M * 8);
       }
     }
     HIPCHK(c, hipStreamSynchronize(st));
@@ -976,9 +1149,9 @@ int append_impl(gpc_post* po, const double* m_star, const double* sn2_star, doub
     HIPCHK(c, hipMemcpy2DAsync(nal.p, (size_t)npn * 8, po->alpha.p, (size_t)np * 8, (size_t)np * 8, S,
                                hipMemcpyDeviceToDevice, st));
     HIPCHK(c, hipStreamSynchronize(st));
-    po->A.release();
-    po->W.release();
-    po->alpha.release();
+    c->pool_give(po->A);
+    c->pool_give(po->W);
+    c->pool_give(po->alpha);
     po->A = nA;
     po->W = nW;
     po->alpha = nal;
@@ -1148,6 +1321,8 @@ void gpc_destroy(gpc_ctx* c) {
                     &c->dmb,  &c->dsn2b, &c->mg,  &c->ng,   &c->ks,   &c->vb,   &c->xss,  &c->pout, &c->kss,
                     &c->dbg1, &c->dbg2,  &c->dbg3, &c->tpart};
   for (DevBuf* b : bufs) b->release();
+  c->pool_drain();
+  c->pin.release();
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
   if (c->ev_up) (void)hipEventDestroy(c->ev_up);
@@ -1181,7 +1356,8 @@ int gpc_set_data(gpc_ctx* c, const double* X, const double* y, int N, int D) {
   if (!X || !y || N <= 0 || D <= 0) FAIL(c, "gpc_set_data: X, y must be non-null and N, D positive");
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, c->dX.ensure((size_t)N * D * sizeof(double)));
-  HIPCHK(c, hipMemcpyAsync(c->dX.p, X, (size_t)N * D * sizeof(double), hipMemcpyHostToDevice, c->st));
+  c->pin.begin();
+  HIPCHK(c, c->pin.up(c->dX.p, X, (size_t)N * D * sizeof(double), c->st));
   HIPCHK(c, hipStreamSynchronize(c->st));
   c->hy.assign(y, y + N);
   c->N = N;
@@ -1218,8 +1394,9 @@ int gpc_kernel(gpc_ctx* c, int kernel_id, int degree, const double* hyp_cov, con
   double* d_xb = d_xa + (size_t)N * D;
   double* d_mul = d_xb + (size_t)Mc * D;
   double* d_div = d_mul + D;
-  HIPCHK(c, hipMemcpyAsync(d_xa, X, (size_t)N * D * 8, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(d_xb, Xstar ? Xstar : X, (size_t)Mc * D * 8, hipMemcpyHostToDevice, st));
+  c->pin.begin();
+  HIPCHK(c, c->pin.up(d_xa, X, (size_t)N * D * 8, st));
+  HIPCHK(c, c->pin.up(d_xb, Xstar ? Xstar : X, (size_t)Mc * D * 8, st));
   HIPCHK(c, hipMemcpyAsync(d_mul, mul.data(), D * 8, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(d_div, dv.data(), D * 8, hipMemcpyHostToDevice, st));
   double* s_xa = c->dbg2.as<double>();
@@ -1233,9 +1410,10 @@ int gpc_kernel(gpc_ctx* c, int kernel_id, int degree, const double* hyp_cov, con
   hipLaunchKernelGGL(full_cov_kernel, dim3((Mc + 63) / 64, (N + 3) / 4), dim3(64, 4), 0, st, cd,
                      (const double*)s_xa, (const double*)s_xb, sf2, rqa, N, Mc, d_K, d_dK);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(K, d_K, nK * 8, hipMemcpyDeviceToHost, st));
-  if (dK) HIPCHK(c, hipMemcpyAsync(dK, d_dK, ndK * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, c->pin.down(K, d_K, nK * 8, st));
+  if (dK) HIPCHK(c, c->pin.down(dK, d_dK, ndK * 8, st));
   HIPCHK(c, hipStreamSynchronize(st));
+  c->pin.finish();
   return 0;
 }
 
@@ -1249,8 +1427,10 @@ int gpc_nll_batch(gpc_ctx* c, int kernel_id, int degree, int dtype, int S, const
   if (want_grad && (!dnlz || (mean_N > 0 && !dm) || (noise_N > 0 && !dsn2)))
     FAIL(c, "gpc_nll_batch: gradient requested without dnlz/dm/dsn2");
   HIPCHK(c, hipSetDevice(c->device));
+  HostClock hc("nll");
   Batch b;
   fill_batch(c, b, kernel_id, degree, S, hyp_cov, m, sn2, sn2_is_vector);
+  hc.lap("fill_batch");
   if (dtype == GPC_F64)
     return nll_impl<double>(c, b, want_grad, dm, mean_N, dsn2, noise_N, nlz, dnlz, sn2_mult, L_chol, info);
   return nll_impl<float>(c, b, want_grad, dm, mean_N, dsn2, noise_N, nlz, dnlz, sn2_mult, L_chol, info);
@@ -1276,9 +1456,9 @@ int gpc_posterior_batch(gpc_ctx* c, int kernel_id, int degree, int dtype, int S,
   rc = (dtype == GPC_F64) ? post_impl<double>(c, b, po, sn2_mult, L_chol, info)
                           : post_impl<float>(c, b, po, sn2_mult, L_chol, info);
   if (rc) {
-    po->A.release();
-    po->W.release();
-    po->alpha.release();
+    c->pool_give(po->A);
+    c->pool_give(po->W);
+    c->pool_give(po->alpha);
     delete po;
     return rc;
   }
@@ -1292,10 +1472,8 @@ int gpc_post_fetch(gpc_post* po, int s, double* alpha, double* sW, double* L) {
   if (s < 0 || s >= po->S) FAIL(c, "gpc_post_fetch: sample index out of range");
   HIPCHK(c, hipSetDevice(c->device));
   const int N = po->N, npad = po->npad;
-  if (alpha) {
-    HIPCHK(c, hipMemcpyAsync(alpha, po->alpha.as<double>() + (size_t)s * npad, N * sizeof(double),
-                             hipMemcpyDeviceToHost, c->st));
-  }
+  c->pin.begin();
+  if (alpha) HIPCHK(c, c->pin.down(alpha, po->alpha.as<double>() + (size_t)s * npad, N * sizeof(double), c->st));
   if (sW)
     for (int i = 0; i < N; ++i) sW[i] = po->sW[s];
   if (L) {
@@ -1311,9 +1489,10 @@ int gpc_post_fetch(gpc_post* po, int s, double* alpha, double* sW, double* L) {
                          (const float*)(po->A.as<float>() + (size_t)s * npad * npad), npad, N, mode,
                          c->dbg3.as<double>());
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(L, c->dbg3.p, (size_t)N * N * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, c->pin.down(L, c->dbg3.p, (size_t)N * N * 8, c->st));
   }
   HIPCHK(c, hipStreamSynchronize(c->st));
+  c->pin.finish();
   return 0;
 }
 
@@ -1321,9 +1500,9 @@ int gpc_post_free(gpc_post* po) {
   if (!po) return 0;
   (void)hipSetDevice(po->ctx->device);
   (void)hipStreamSynchronize(po->ctx->st);
-  po->A.release();
-  po->W.release();
-  po->alpha.release();
+  po->ctx->pool_give(po->A);
+  po->ctx->pool_give(po->W);
+  po->ctx->pool_give(po->alpha);
   delete po;
   return 0;
 }
