@@ -29,7 +29,15 @@ struct MM<double> {
   using vec_t = double __attribute__((ext_vector_type(2)));  // 16-byte global/LDS vector
   static constexpr int VEC = 2;
   static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) {
+#if defined(GPC_MFMA_AGPR)
+    asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    return c;
+#elif defined(GPC_MFMA_VASM)
+    asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    return c;
+#else
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+#endif
   }
   static __device__ __forceinline__ int row_of(int lane, int r) { return (lane >> 4) + 4 * r; }
 };

@@ -200,17 +200,28 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(GemmArgs g) {
         g2r<T, BKM, BT, NT>(rb, B, g.ldb, n0, k0 + (it + 1) * BKT, t);
       }
       if (g.flags & 1) __builtin_amdgcn_s_setprio(1);
+      // fragments are double buffered in registers: the LDS reads of k-step s+1 are issued
+      // ahead of the 16 MFMAs of k-step s, so only the first k-step of a slab waits on LDS
+      T af[2][MRM], bf[2][MRN];
 #pragma unroll
-      for (int kk = 0; kk < BKT; kk += 4) {
-        T af[MRM], bf[MRN];
+      for (int i = 0; i < MRM; ++i) af[0][i] = frag<T, AKM, BT>(a_s, wr * WTM + i * 16, 0, lane);
 #pragma unroll
-        for (int i = 0; i < MRM; ++i) af[i] = frag<T, AKM, BT>(a_s, wr * WTM + i * 16, kk, lane);
+      for (int j = 0; j < MRN; ++j) bf[0][j] = frag<T, BKM, BT>(b_s, wc * WTN + j * 16, 0, lane);
 #pragma unroll
-        for (int j = 0; j < MRN; ++j) bf[j] = frag<T, BKM, BT>(b_s, wc * WTN + j * 16, kk, lane);
+      for (int ks = 0; ks < BKT / 4; ++ks) {
+        const int c = ks & 1;
+        if (ks + 1 < BKT / 4) {
+#pragma unroll
+          for (int i = 0; i < MRM; ++i) af[c ^ 1][i] = frag<T, AKM, BT>(a_s, wr * WTM + i * 16, (ks + 1) * 4, lane);
+#pragma unroll
+          for (int j = 0; j < MRN; ++j) bf[c ^ 1][j] = frag<T, BKM, BT>(b_s, wc * WTN + j * 16, (ks + 1) * 4, lane);
+        }
 #pragma unroll
         for (int i = 0; i < MRM; ++i)
 #pragma unroll
-          for (int j = 0; j < MRN; ++j) acc[i][j] = MM<T>::mma(af[i], bf[j], acc[i][j]);
+          for (int j = 0; j < MRN; ++j) acc[i][j] = MM<T>::mma(af[c][i], bf[c][j], acc[i][j]);
+        __builtin_amdgcn_sched_group_barrier(0x100, MRM + MRN, 0);  // the next k-step's LDS reads first
+        __builtin_amdgcn_sched_group_barrier(0x008, MRM * MRN, 0);  // then this k-step's MFMAs
       }
       if (g.flags & 1) __builtin_amdgcn_s_setprio(0);
       if (g.flags & 2) continue;
