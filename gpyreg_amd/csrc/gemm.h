@@ -25,6 +25,8 @@
 #pragma once
 #include "common.h"
 
+#include <type_traits>
+
 namespace gpc {
 
 constexpr int BKT = 16;       // k-slab per LDS stage
@@ -47,36 +49,42 @@ struct GemmArgs {
   int beta;  // 0 or 1
   int klo, khi, lower_only;
   int tiles_m, tiles_n;
-  int flags;  // experiment switches (GPC_GEMM_FLAGS): 1 setprio, 2 no restage (timing only),
-              // 4 no global loads (timing only)
+  int flags;  // reserved for experiment switches (GPC_GEMM_FLAGS); unused by the kernel
 };
 inline int g_gemm_flags = 0;
 
+// Staging addresses are split into a block-uniform pointer `u` (tile origin, advanced by the
+// caller one k-slab at a time: scalar adds only) and a per-thread element offset fixed for the
+// whole k-loop, so the loop carries no per-thread 64-bit address arithmetic and the loads use
+// the scalar-base + 32-bit-offset form of global_load.
 template <typename T, bool KM, int BT, int NT>
-__device__ __forceinline__ void g2r(typename MM<T>::vec_t (&r)[(BT * BKT) / (NT * MM<T>::VEC)],
-                                    const T* __restrict__ g, int ld, int r0, int k0, int t) {
-  using vec_t = typename MM<T>::vec_t;
+__device__ __forceinline__ unsigned stage_toff(int ld, int t) {
   constexpr int VEC = MM<T>::VEC;
-  constexpr int NV = (BT * BKT) / (NT * VEC);
   if constexpr (!KM) {  // stored [row][k]
-    constexpr int TPR = BKT / VEC;   // threads per row
-    constexpr int RPP = NT / TPR;    // rows per pass
-#pragma unroll
-    for (int p = 0; p < NV; ++p) {
-      const int row = t / TPR + p * RPP;
-      const int kc = (t % TPR) * VEC;
-      r[p] = *reinterpret_cast<const vec_t*>(g + (size_t)(r0 + row) * ld + k0 + kc);
-    }
+    constexpr int TPR = BKT / VEC;  // threads per row
+    return (unsigned)(t / TPR) * (unsigned)ld + (unsigned)((t % TPR) * VEC);
   } else {  // stored [k][row]
     constexpr int VPR = BT / VEC;  // vectors per k-row
-#pragma unroll
-    for (int p = 0; p < NV; ++p) {
-      const int v = t + NT * p;
-      const int k = v / VPR;
-      const int mc = (v % VPR) * VEC;
-      r[p] = *reinterpret_cast<const vec_t*>(g + (size_t)(k0 + k) * ld + r0 + mc);
-    }
+    return (unsigned)(t / VPR) * (unsigned)ld + (unsigned)((t % VPR) * VEC);
   }
+}
+// elements between consecutive passes p of one thread (block-uniform)
+template <typename T, bool KM, int BT, int NT>
+__device__ __forceinline__ size_t stage_pstride(int ld) {
+  constexpr int VEC = MM<T>::VEC;
+  if constexpr (!KM)
+    return (size_t)(NT / (BKT / VEC)) * ld;
+  else
+    return (size_t)(NT / (BT / VEC)) * ld;
+}
+template <typename T, bool KM, int BT, int NT>
+__device__ __forceinline__ void g2r(typename MM<T>::vec_t (&r)[(BT * BKT) / (NT * MM<T>::VEC)],
+                                    const T* __restrict__ u, size_t pstride, unsigned toff) {
+  using vec_t = typename MM<T>::vec_t;
+  constexpr int NV = (BT * BKT) / (NT * MM<T>::VEC);
+  static_assert(KM ? (NT % (BT / MM<T>::VEC) == 0) : (NT % (BKT / MM<T>::VEC) == 0), "pass layout");
+#pragma unroll
+  for (int p = 0; p < NV; ++p) r[p] = *reinterpret_cast<const vec_t*>(u + p * pstride + toff);
 }
 
 template <typename T, bool KM, int BT, int NT>
@@ -185,53 +193,104 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(GemmArgs g) {
 
   if (nk > 0) {
     vec_t ra[NV], rb[NV];
-    g2r<T, AKM, BT, NT>(ra, A, g.lda, m0, k0, t);
-    g2r<T, BKM, BT, NT>(rb, B, g.ldb, n0, k0, t);
+    const unsigned toa = stage_toff<T, AKM, BT, NT>(g.lda, t), tob = stage_toff<T, BKM, BT, NT>(g.ldb, t);
+    const size_t psa = stage_pstride<T, AKM, BT, NT>(g.lda), psb = stage_pstride<T, BKM, BT, NT>(g.ldb);
+    const size_t stepa = AKM ? (size_t)BKT * g.lda : (size_t)BKT, stepb = BKM ? (size_t)BKT * g.ldb : (size_t)BKT;
+    const T* ua = AKM ? A + (size_t)k0 * g.lda + m0 : A + (size_t)m0 * g.lda + k0;
+    const T* ub = BKM ? B + (size_t)k0 * g.ldb + n0 : B + (size_t)n0 * g.ldb + k0;
+    g2r<T, AKM, BT, NT>(ra, ua, psa, toa);
+    g2r<T, BKM, BT, NT>(rb, ub, psb, tob);
     r2s<T, AKM, BT, NT>(smem, ra, t);
     r2s<T, BKM, BT, NT>(smem + OPSZ, rb, t);
+    // slab 1 is in flight while slab 0 is multiplied (nk is a multiple of 8)
+    ua += stepa;
+    ub += stepb;
+    g2r<T, AKM, BT, NT>(ra, ua, psa, toa);
+    g2r<T, BKM, BT, NT>(rb, ub, psb, tob);
     __syncthreads();
-    for (int it = 0; it < nk; ++it) {
-      const int cur = it & 1;
-      const T* a_s = smem + cur * 2 * OPSZ;
+
+    // Software pipeline of one k-slab (4 k-steps of MRM x MRN MFMAs) out of LDS stage CUR.
+    // Measured on MI355X (tools/mfma_ladder.hip, profiles/r01g_mfma_ladder.txt): the MFMA pipe
+    // stays ~98% busy only if no two memory instructions are issued back to back, so
+    //   * fragments are double buffered in registers, the LDS reads of k-step s+1 go out ahead
+    //     of the MFMAs of k-step s;
+    //   * the LDS writes of the next slab (stage CUR^1) are spread between the MFMAs of k-step 2,
+    //   * the block barrier sits between k-steps 2 and 3, so the first fragments of the next
+    //     slab are read during k-step 3 and no k-step waits on LDS latency;
+    //   * the global loads of the slab after next are spread between the MFMAs of k-step 3
+    //     (in flight during k-steps 0-1 of the next slab; consumed by its k-step 2).
+    // WR: a next slab exists (ra/rb hold it); LD: a slab after next exists.
+    T af[2][MRM], bf[2][MRN];
+    auto load_frags = [&](int set, const T* a_s, const T* b_s, int kk) {
+#pragma unroll
+      for (int i = 0; i < MRM; ++i) af[set][i] = frag<T, AKM, BT>(a_s, wr * WTM + i * 16, kk, lane);
+#pragma unroll
+      for (int j = 0; j < MRN; ++j) bf[set][j] = frag<T, BKM, BT>(b_s, wc * WTN + j * 16, kk, lane);
+    };
+    auto mfmas = [&](int set) {
+#pragma unroll
+      for (int i = 0; i < MRM; ++i)
+#pragma unroll
+        for (int j = 0; j < MRN; ++j) acc[i][j] = MM<T>::mma(af[set][i], bf[set][j], acc[i][j]);
+    };
+    constexpr int NMEM = 2 * NV;                    // memory instructions per slab and direction
+    constexpr int PER = (MRM * MRN) / NMEM;         // MFMAs between two of them
+    static_assert(PER >= 1 && PER * NMEM == MRM * MRN, "interleave pattern");
+    static_assert(BKT == 16, "the slab pipeline is written for 4 k-steps");
+    auto slab = [&](auto cur_c, auto wr_c, auto ld_c) {
+      constexpr int CUR = decltype(cur_c)::value;
+      constexpr bool WR = decltype(wr_c)::value, LD = decltype(ld_c)::value;
+      const T* a_s = smem + CUR * 2 * OPSZ;
       const T* b_s = a_s + OPSZ;
-      const bool more = (it + 1 < nk);
-      if (more && !(g.flags & 4)) {
-        g2r<T, AKM, BT, NT>(ra, A, g.lda, m0, k0 + (it + 1) * BKT, t);
-        g2r<T, BKM, BT, NT>(rb, B, g.ldb, n0, k0 + (it + 1) * BKT, t);
-      }
-      if (g.flags & 1) __builtin_amdgcn_s_setprio(1);
-      // fragments are double buffered in registers: the LDS reads of k-step s+1 are issued
-      // ahead of the 16 MFMAs of k-step s, so only the first k-step of a slab waits on LDS
-      T af[2][MRM], bf[2][MRN];
-#pragma unroll
-      for (int i = 0; i < MRM; ++i) af[0][i] = frag<T, AKM, BT>(a_s, wr * WTM + i * 16, 0, lane);
-#pragma unroll
-      for (int j = 0; j < MRN; ++j) bf[0][j] = frag<T, BKM, BT>(b_s, wc * WTN + j * 16, 0, lane);
-#pragma unroll
-      for (int ks = 0; ks < BKT / 4; ++ks) {
-        const int c = ks & 1;
-        if (ks + 1 < BKT / 4) {
-#pragma unroll
-          for (int i = 0; i < MRM; ++i) af[c ^ 1][i] = frag<T, AKM, BT>(a_s, wr * WTM + i * 16, (ks + 1) * 4, lane);
-#pragma unroll
-          for (int j = 0; j < MRN; ++j) bf[c ^ 1][j] = frag<T, BKM, BT>(b_s, wc * WTN + j * 16, (ks + 1) * 4, lane);
-        }
-#pragma unroll
-        for (int i = 0; i < MRM; ++i)
-#pragma unroll
-          for (int j = 0; j < MRN; ++j) acc[i][j] = MM<T>::mma(af[c][i], bf[c][j], acc[i][j]);
-        __builtin_amdgcn_sched_group_barrier(0x100, MRM + MRN, 0);  // the next k-step's LDS reads first
-        __builtin_amdgcn_sched_group_barrier(0x008, MRM * MRN, 0);  // then this k-step's MFMAs
-      }
-      if (g.flags & 1) __builtin_amdgcn_s_setprio(0);
-      if (g.flags & 2) continue;
-      if (more) {
-        T* a_n = smem + (cur ^ 1) * 2 * OPSZ;
+      T* a_n = smem + (CUR ^ 1) * 2 * OPSZ;
+      load_frags(1, a_s, b_s, 4);
+      mfmas(0);
+      __builtin_amdgcn_sched_group_barrier(0x100, MRM + MRN, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, MRM * MRN, 0);
+      load_frags(0, a_s, b_s, 8);
+      mfmas(1);
+      __builtin_amdgcn_sched_group_barrier(0x100, MRM + MRN, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, MRM * MRN, 0);
+      load_frags(1, a_s, b_s, 12);
+      mfmas(0);
+      if constexpr (WR) {
         r2s<T, AKM, BT, NT>(a_n, ra, t);
         r2s<T, BKM, BT, NT>(a_n + OPSZ, rb, t);
       }
+      __builtin_amdgcn_sched_group_barrier(0x100, MRM + MRN, 0);
+#pragma unroll
+      for (int q = 0; q < NMEM; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+        if constexpr (WR) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
       __syncthreads();
+      if constexpr (LD) {
+        ua += stepa;
+        ub += stepb;
+        g2r<T, AKM, BT, NT>(ra, ua, psa, toa);
+        g2r<T, BKM, BT, NT>(rb, ub, psb, tob);
+      }
+      if constexpr (WR) load_frags(0, a_n, a_n + OPSZ, 0);
+      mfmas(1);
+      if constexpr (WR) __builtin_amdgcn_sched_group_barrier(0x100, MRM + MRN, 0);
+#pragma unroll
+      for (int q = 0; q < NMEM; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+        if constexpr (LD) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    load_frags(0, smem, smem + OPSZ, 0);
+    int it = 0;
+    for (; it + 3 < nk; it += 2) {
+      slab(I0{}, std::true_type{}, std::true_type{});
+      slab(I1{}, std::true_type{}, std::true_type{});
     }
+    // k-ranges are 128-granular (8 slabs), so exactly two slabs are left: the last one that
+    // still stages a successor, and the last one
+    slab(I0{}, std::true_type{}, std::false_type{});
+    slab(I1{}, std::false_type{}, std::false_type{});
   }
 
   const T alpha = (T)g.alpha;

@@ -38,7 +38,27 @@ def body(variant):
     for ks in range(4):
         fs = ks & 1
         ms = kstep_mfmas(fs)
-        if rd:
+        if variant.get("barrier") == "ks2" and ks == 3:
+            L.append("s_barrier")
+        if variant.get("spread") and ks in (2, 3):
+            extra = []
+            if ks == 2:
+                L.append("s_waitcnt vmcnt(0)")
+                extra = [f"ds_write_b128 v201, v[{160+4*q}:{163+4*q}] offset:{q*2048}" for q in range(8)]
+            else:
+                L += ["s_add_u32 s24, s24, 0x80000", "s_addc_u32 s25, s25, 0", "s_add_u32 s26, s26, 0x80000", "s_addc_u32 s27, s27, 0",
+                      "s_add_u32 s21, s21, 1", "s_cmp_lt_u32 s21, 240", "s_cselect_b32 s24, s24, s28", "s_cselect_b32 s25, s25, s29",
+                      "s_cselect_b32 s26, s26, s30", "s_cselect_b32 s27, s27, s31", "s_cselect_b32 s21, s21, 0"]
+                extra = [f"global_load_dwordx4 v[{160+4*q}:{163+4*q}], v{204+q}, s[24:25]" for q in range(4)] + \
+                        [f"global_load_dwordx4 v[{176+4*q}:{179+4*q}], v{204+q}, s[26:27]" for q in range(4)]
+            r = reads(fs ^ 1, rd, 32 * ((ks + 1) % 4))
+            L += r
+            for i, m in enumerate(ms):
+                L.append(m)
+                if i % 2 == 1:
+                    L.append(extra[i // 2])
+            L.append("s_waitcnt lgkmcnt(0)")
+        elif rd:
             r = reads(fs ^ 1, rd, 32 * ((ks + 1) % 4))
             if variant.get("interleave"):   # spread the reads between the MFMAs
                 step = len(ms) // len(r)
@@ -53,16 +73,37 @@ def body(variant):
             L.append("s_waitcnt lgkmcnt(0)")
         else:
             L += ms
-        if ks == 0 and variant.get("gload"):
+        if variant.get("mid") and ks == 1:
+            L.append("s_waitcnt vmcnt(0)")
+            for q in range(8):
+                L.append(f"ds_write_b128 v201, v[{160+4*q}:{163+4*q}] offset:{q*2048}")
+        if ks == (1 if variant.get("mid") else 0) and variant.get("gload") == "stream":
+            # k-major panels like lauum: 16 rows of a 4096-wide matrix per slab, two operands (s[24:25], s[26:27])
+            L.append("s_add_u32 s24, s24, 0x80000")   # 16 rows * 4096 * 8 bytes
+            L.append("s_addc_u32 s25, s25, 0")
+            L.append("s_add_u32 s26, s26, 0x80000")
+            L.append("s_addc_u32 s27, s27, 0")
+            L.append("s_add_u32 s21, s21, 1")
+            L.append("s_cmp_lt_u32 s21, 240")          # wrap before the end of the 4096-row sample
+            L.append("s_cselect_b32 s24, s24, s28")
+            L.append("s_cselect_b32 s25, s25, s29")
+            L.append("s_cselect_b32 s26, s26, s30")
+            L.append("s_cselect_b32 s27, s27, s31")
+            L.append("s_cselect_b32 s21, s21, 0")
+            for q in range(4):
+                L.append(f"global_load_dwordx4 v[{160+4*q}:{163+4*q}], v{204+q}, s[24:25]")
+            for q in range(4):
+                L.append(f"global_load_dwordx4 v[{176+4*q}:{179+4*q}], v{204+q}, s[26:27]")
+        elif ks == 0 and variant.get("gload") is True:
             for q in range(8):
                 L.append(f"global_load_dwordx4 v[{160+4*q}:{163+4*q}], v[202:203], off offset:{q*512}")
-    if variant.get("gload"):
+    if variant.get("gload") and not variant.get("mid"):
         L.append("s_waitcnt vmcnt(0)")
-    if variant.get("writes"):
+    if variant.get("writes") and not variant.get("mid"):
         for q in range(8):
             L.append(f"ds_write_b128 v201, v[{160+4*q}:{163+4*q}] offset:{q*2048}")
         L.append("s_waitcnt lgkmcnt(0)")
-    if variant.get("barrier"):
+    if variant.get("barrier") is True:
         L.append("s_barrier")
     return L
 
@@ -74,6 +115,12 @@ VARIANTS = [
     ("read2 + barrier per slab", {"reads": "read2", "barrier": True}),
     ("read2 + ds_write_b128 x8 + barrier", {"reads": "read2", "writes": True, "barrier": True}),
     ("read2 + global_load x8 + ds_write x8 + barrier (full slab pipeline)", {"reads": "read2", "gload": True, "writes": True, "barrier": True}),
+    ("full slab pipeline, global loads streaming 16-row panels of 4096-wide matrices", {"reads": "read2", "gload": "stream", "writes": True, "barrier": True}),
+    ("streaming, LDS writes + next loads issued mid-slab (after k-step 1)", {"reads": "read2", "gload": "stream", "writes": True, "barrier": True, "mid": True}),
+    ("same with interleaved fragment reads", {"reads": "read2", "interleave": True, "gload": "stream", "writes": True, "barrier": True, "mid": True}),
+    ("mid-slab writes, barrier after k-step 2 (next slab's first fragments prefetched during k-step 3)", {"reads": "read2", "gload": "stream", "writes": True, "barrier": "ks2", "mid": True}),
+    ("LDS writes spread over k-step 2's MFMAs, global loads over k-step 3's", {"reads": "read2", "spread": True, "barrier": True}),
+    ("streaming global loads only", {"gload": "stream"}),
     ("barrier only", {"barrier": True}),
     ("global_load x8 only", {"gload": True}),
 ]
@@ -86,6 +133,17 @@ def kernel(idx, variant):
     asm.append("v_mov_b32 v201, %3")
     asm.append("v_mov_b32 v202, %4")
     asm.append("v_mov_b32 v203, %5")
+    for q in range(4):
+        asm.append(f"v_mov_b32 v{204+q}, %{6+q}")
+    asm.append("s_mov_b32 s24, %10")
+    asm.append("s_mov_b32 s25, %11")
+    asm.append("s_mov_b32 s26, %12")
+    asm.append("s_mov_b32 s27, %13")
+    asm.append("s_mov_b32 s28, s24")
+    asm.append("s_mov_b32 s29, s25")
+    asm.append("s_mov_b32 s30, s26")
+    asm.append("s_mov_b32 s31, s27")
+    asm.append("s_mov_b32 s21, 0")
     for r in range(0, 192):
         asm.append(f"v_mov_b32 v{r}, 0")
     asm.append("LOOP%=:")
@@ -96,9 +154,9 @@ def kernel(idx, variant):
     asm.append("s_nop 7")
     asm.append("v_mov_b32 %0, v0")
     text = "\n".join(f'      "{a}\\n"' for a in asm)
-    clob = ", ".join(f'"v{r}"' for r in range(0, 204))
+    clob = ", ".join(f'"v{r}"' for r in range(0, 208)) + ", " + ", ".join(f'"s{r}"' for r in range(21, 32))
     return f"""
-__global__ __launch_bounds__(256) void k{idx}(float* out, int iters, const double* gsrc) {{
+__global__ __launch_bounds__(256) void k{idx}(float* out, int iters, const double* gsrc, const double* big) {{
   extern __shared__ double lds[];
   for (int i = threadIdx.x; i < 8192; i += 256) lds[i] = 1e-3 * (i % 97);
   __syncthreads();
@@ -107,10 +165,17 @@ __global__ __launch_bounds__(256) void k{idx}(float* out, int iters, const doubl
   int waddr = threadIdx.x * 16 + 32768;
   const double* gp = gsrc + (size_t)(blockIdx.x % 64) * 65536 + threadIdx.x * 2;
   unsigned lo = (unsigned)(size_t)gp, hi = (unsigned)((size_t)gp >> 32);
+  // streaming operands: sample = block % 16 (4096 x 4096 doubles each), column panels of 128
+  const double* pa = big + (size_t)(blockIdx.x % 16) * 4096 * 4096 + ((blockIdx.x / 16) % 32) * 128;
+  const double* pb = big + (size_t)(blockIdx.x % 16) * 4096 * 4096 + ((blockIdx.x / 16 + 7) % 32) * 128;
+  unsigned vo0 = ((threadIdx.x / 64 + 0) * 4096 + (threadIdx.x % 64) * 2) * 8, vo1 = vo0 + 4 * 4096 * 8, vo2 = vo0 + 8 * 4096 * 8,
+           vo3 = vo0 + 12 * 4096 * 8;
+  unsigned alo = __builtin_amdgcn_readfirstlane((unsigned)(size_t)pa), ahi = __builtin_amdgcn_readfirstlane((unsigned)((size_t)pa >> 32));
+  unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)(size_t)pb), bhi = __builtin_amdgcn_readfirstlane((unsigned)((size_t)pb >> 32));
   float r;
   asm volatile(
 {text}
-      : "=v"(r) : "s"(iters), "v"(raddr), "v"(waddr), "v"(lo), "v"(hi) : {clob}, "s20", "scc", "memory");
+      : "=v"(r) : "s"(iters), "v"(raddr), "v"(waddr), "v"(lo), "v"(hi), "v"(vo0), "v"(vo1), "v"(vo2), "v"(vo3), "s"(alo), "s"(ahi), "s"(blo), "s"(bhi) : {clob}, "s20", "scc", "memory");
   out[blockIdx.x * 256 + threadIdx.x] = r;
 }}
 """
@@ -119,10 +184,13 @@ src = ["// generated by tools/gen_mfma_ladder.py -- do not edit", "#include <hip
 for i, (name, v) in enumerate(VARIANTS):
     src.append(kernel(i, v))
 src.append("""
-typedef void (*kern_t)(float*, int, const double*);
+typedef void (*kern_t)(float*, int, const double*, const double*);
 int main() {
   float* d; hipMalloc(&d, 4096 * 256 * 4);
   double* g; hipMalloc(&g, 64 * 65536 * 8 + (1 << 20)); hipMemset(g, 0, 64 * 65536 * 8 + (1 << 20));
+  double* big; size_t bigsz = (size_t)16 * 4096 * 4096 * 8 + (8 << 20);
+  if (hipMalloc(&big, bigsz) != hipSuccess) { printf("big alloc failed\\n"); return 1; }
+  hipMemset(big, 0, bigsz);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int iters = 4000;  // slabs of 64 MFMAs
   struct { kern_t k; const char* name; } ks[] = {""")
@@ -133,10 +201,10 @@ src.append("""  };
     for (int wgs : {256, 512}) {
       const unsigned dyn = 72 * 1024;  // two blocks per CU, like the GEMM
       hipFuncSetAttribute((const void*)e.k, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
-      hipLaunchKernelGGL(e.k, dim3(wgs), dim3(256), dyn, 0, d, 50, g);
+      hipLaunchKernelGGL(e.k, dim3(wgs), dim3(256), dyn, 0, d, 50, g, big);
       hipDeviceSynchronize();
       hipEventRecord(e0);
-      hipLaunchKernelGGL(e.k, dim3(wgs), dim3(256), dyn, 0, d, iters, g);
+      hipLaunchKernelGGL(e.k, dim3(wgs), dim3(256), dyn, 0, d, iters, g, big);
       hipEventRecord(e1);
       hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);
