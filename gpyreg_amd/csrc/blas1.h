@@ -205,18 +205,35 @@ __global__ void rect_copy_kernel(const T* __restrict__ src, long long sS, int ld
   dst[(size_t)blockIdx.z * sD + (size_t)r * ldd + c] = src[(size_t)blockIdx.z * sS + (size_t)r * lds_ + c];
 }
 
-// register-resident MFMA issue loop: the measured ceiling the roofline is quoted against
+// register-resident MFMA issue loop: the measured ceiling the roofline is quoted against.
+// The 4 x 4 accumulator block of the GEMM's k-step, written as one asm block so that the
+// compiler cannot put register copies between the MFMAs (a plain C++ loop over an accumulator
+// array measured 105 instead of 64 cycles per v_mfma_f64_16x16x4_f64 for that reason;
+// tools_mfma_scaling.hip).  NACC is kept as a template parameter for the C ABI's variants:
+// every variant issues the same 16 independent MFMAs per iteration.
+#define GPC_PEAK_M(op, c, a, b) op " %" #c ", %" #a ", %" #b ", %" #c "\n"
+#define GPC_PEAK_BLOCK(op)                                                                                        \
+  asm volatile(GPC_PEAK_M(op, 0, 16, 20) GPC_PEAK_M(op, 1, 16, 21) GPC_PEAK_M(op, 2, 16, 22) GPC_PEAK_M(op, 3, 16, 23)   \
+               GPC_PEAK_M(op, 4, 17, 20) GPC_PEAK_M(op, 5, 17, 21) GPC_PEAK_M(op, 6, 17, 22) GPC_PEAK_M(op, 7, 17, 23)   \
+               GPC_PEAK_M(op, 8, 18, 20) GPC_PEAK_M(op, 9, 18, 21) GPC_PEAK_M(op, 10, 18, 22) GPC_PEAK_M(op, 11, 18, 23) \
+               GPC_PEAK_M(op, 12, 19, 20) GPC_PEAK_M(op, 13, 19, 21) GPC_PEAK_M(op, 14, 19, 22) GPC_PEAK_M(op, 15, 19, 23) \
+               : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]),        \
+                 "+v"(c[8]), "+v"(c[9]), "+v"(c[10]), "+v"(c[11]), "+v"(c[12]), "+v"(c[13]), "+v"(c[14]), "+v"(c[15])  \
+               : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3))
 template <typename T, int NACC>
 __global__ __launch_bounds__(256) void mfma_peak_kernel(T* out, int iters, long long* clk) {
   using acc_t = typename MM<T>::acc_t;
-  acc_t acc[NACC];
+  acc_t c[16];
 #pragma unroll
-  for (int i = 0; i < NACC; ++i) acc[i] = acc_t{0, 0, 0, 0};
-  T a = (T)(threadIdx.x * 1e-3), bq = (T)(1.0 + threadIdx.x * 1e-4);
+  for (int i = 0; i < 16; ++i) c[i] = acc_t{0, 0, 0, 0};
+  const T a0 = (T)(threadIdx.x * 1e-3), a1 = a0 + (T)1, a2 = a0 + (T)2, a3 = a0 + (T)3;
+  const T b0 = (T)(1.0 + threadIdx.x * 1e-4), b1 = b0 + (T)1, b2 = b0 + (T)2, b3 = b0 + (T)3;
   const long long c0 = clock64(), w0 = wall_clock64();
-  for (int it = 0; it < iters; ++it) {
-#pragma unroll
-    for (int i = 0; i < NACC; ++i) acc[i] = MM<T>::mma(a, bq, acc[i]);
+  for (int it = 0; it < iters * NACC / 16; ++it) {
+    if constexpr (sizeof(T) == 8)
+      GPC_PEAK_BLOCK("v_mfma_f64_16x16x4_f64");
+    else
+      GPC_PEAK_BLOCK("v_mfma_f32_16x16x4_f32");
   }
   const long long c1 = clock64(), w1 = wall_clock64();
   if (clk && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -225,9 +242,11 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(T* out, int iters, long 
   }
   T s = 0;
 #pragma unroll
-  for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  for (int i = 0; i < 16; ++i) s += c[i][0] + c[i][1] + c[i][2] + c[i][3];
   out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
 }
+#undef GPC_PEAK_BLOCK
+#undef GPC_PEAK_M
 
 // ---- rank-one append of a training point to resident posteriors (gaussian_process.py:750-844) ----
 // dst[b] ((npn x npn), identity-padded) <- src[b] (np x np top-left block).  grid = (npn/64, npn/4, batch)

@@ -50,6 +50,8 @@ struct GemmArgs {
   int klo, khi, lower_only;
   int tiles_m, tiles_n;
   int flags;  // reserved for experiment switches (GPC_GEMM_FLAGS); unused by the kernel
+  int* ctr;    // persistent launches: zeroed device counter the blocks draw tiles from
+  int ntiles, batch;
 };
 inline int g_gemm_flags = 0;
 
@@ -138,7 +140,7 @@ __device__ __forceinline__ void tri_tile(int tile, int& ti, int& tj) {
 // NW = waves per block: 4 (2 x 2 waves of BT/2 x BT/2) or 8 (2 x 4 waves of BT/2 x BT/4:
 // half the accumulators per wave, so twice the waves per SIMD to cover staging and barriers).
 template <typename T, bool AKM, bool BKM, int BT, int NW>
-__global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const int by, T* __restrict__ smem) {
   using acc_t = typename MM<T>::acc_t;
   using vec_t = typename MM<T>::vec_t;
   constexpr int NT = 64 * NW;
@@ -148,8 +150,6 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(GemmArgs g) {
   constexpr int WTM = BT / 2;          // wave tile rows
   constexpr int WTN = BT / WCOLS;      // wave tile cols
   constexpr int MRM = WTM / 16, MRN = WTN / 16;
-  __shared__ __attribute__((aligned(16))) T smem[4 * OPSZ];
-
   const int t = threadIdx.x;
   const int lane = t & 63, w = t >> 6, wr = w / WCOLS, wc = w % WCOLS;
 
@@ -158,7 +158,6 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(GemmArgs g) {
   // the major index is the one the k-range depends on, which also keeps consecutive
   // blocks on one operand panel.
   int ti, tj;
-  const int bx = blockIdx.x;
   if (g.lower_only) {
     tri_tile(bx, ti, tj);  // ti ascending: longest first for KLO_ROW (lauum), uniform for syrk
   } else if (g.khi == KHI_COL) {
@@ -181,9 +180,9 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(GemmArgs g) {
   if (k1 > g.K) k1 = g.K;
   const int nk = (k1 - k0) / BKT;
 
-  const T* __restrict__ A = reinterpret_cast<const T*>(g.A) + (size_t)blockIdx.y * g.sA;
-  const T* __restrict__ B = reinterpret_cast<const T*>(g.B) + (size_t)blockIdx.y * g.sB;
-  T* __restrict__ C = reinterpret_cast<T*>(g.C) + (size_t)blockIdx.y * g.sC;
+  const T* __restrict__ A = reinterpret_cast<const T*>(g.A) + (size_t)by * g.sA;
+  const T* __restrict__ B = reinterpret_cast<const T*>(g.B) + (size_t)by * g.sB;
+  T* __restrict__ C = reinterpret_cast<T*>(g.C) + (size_t)by * g.sC;
 
   acc_t acc[MRM][MRN];
 #pragma unroll
@@ -309,17 +308,62 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(GemmArgs g) {
       }
 }
 
+template <typename T, bool AKM, bool BKM, int BT, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) T smem[4 * opsz_of(BT)];
+  gemm_tile<T, AKM, BKM, BT, NW>(g, blockIdx.x, blockIdx.y, smem);
+}
+
+// Persistent form for launches with more tiles than block slots: a fixed grid of blocks pulls
+// (tile, sample) pairs off a device counter (longest tiles of every sample first).  The grid is
+// `g_persist_spare` blocks short of two per CU, which leaves that many CUs with one resident
+// GEMM block instead of two: room (registers, LDS) for the leaf / deep-level launches of the
+// other sample group, which otherwise wait for this whole launch to drain
+// (profiles/r01g_coresidency_probe.txt).
+template <typename T, bool AKM, bool BKM, int BT, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 2) void gemm_persist_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) T smem[4 * opsz_of(BT)];
+  __shared__ int next_tile;
+  const int total = g.ntiles * g.batch;
+  for (;;) {
+    if (threadIdx.x == 0) next_tile = atomicAdd(g.ctr, 1);
+    __syncthreads();
+    const int idx = __builtin_amdgcn_readfirstlane(next_tile);
+    __syncthreads();  // everyone holds idx before thread 0 may overwrite it; also fences the LDS stages
+    if (idx >= total) break;
+    gemm_tile<T, AKM, BKM, BT, NW>(g, idx / g.batch, idx % g.batch, smem);
+  }
+}
+
 inline int g_gemm_pad_lds = 0;  // experiment: extra dynamic LDS (bytes) on 128-tile launches
+inline int g_persist_spare = 16;    // tunable: GPC_PERSIST_SPARE (block slots a persistent launch leaves free)
+inline int g_block_slots = 512;     // two 128-tile blocks per CU (set from the device's CU count)
 template <typename T, int BT, int NW>
-inline hipError_t launch_gemm_bt(hipStream_t st, GemmArgs g, bool akm, bool bkm, int batch) {
+inline hipError_t launch_gemm_bt(hipStream_t st, GemmArgs g, bool akm, bool bkm, int batch, int* ctr = nullptr) {
   const int tm = g.M / BT, tn = g.N / BT;
   g.tiles_m = tm;
   g.tiles_n = tn;
   g.flags = g_gemm_flags;
   const int ntiles = g.lower_only ? tm * (tm + 1) / 2 : tm * tn;
   if (ntiles <= 0 || batch <= 0) return hipSuccess;
-  dim3 grid(ntiles, batch), block(64 * NW);
+  g.ntiles = ntiles;
+  g.batch = batch;
+  g.ctr = ctr;
   const unsigned dyn = (BT == 128) ? (unsigned)g_gemm_pad_lds : 0u;
+  const int cap = g_block_slots - g_persist_spare;
+  if (ctr && BT == 128 && NW == 4 && cap > 0 && (long long)ntiles * batch > cap) {
+    dim3 grid(cap), block(64 * NW);
+    if (!akm && !bkm)
+      hipLaunchKernelGGL((gemm_persist_kernel<T, false, false, 128, 4>), grid, block, dyn, st, g);
+    else if (!akm && bkm)
+      hipLaunchKernelGGL((gemm_persist_kernel<T, false, true, 128, 4>), grid, block, dyn, st, g);
+    else if (akm && bkm)
+      hipLaunchKernelGGL((gemm_persist_kernel<T, true, true, 128, 4>), grid, block, dyn, st, g);
+    else
+      hipLaunchKernelGGL((gemm_persist_kernel<T, true, false, 128, 4>), grid, block, dyn, st, g);
+    return hipGetLastError();
+  }
+  dim3 grid(ntiles, batch), block(64 * NW);
   if (!akm && !bkm)
     hipLaunchKernelGGL((gemm_kernel<T, false, false, BT, NW>), grid, block, dyn, st, g);
   else if (!akm && bkm)
@@ -337,13 +381,14 @@ inline hipError_t launch_gemm_bt(hipStream_t st, GemmArgs g, bool akm, bool bkm,
 inline int g_small_launch_blocks = 1100;  // tunable: GPC_SMALL_BLOCKS
 inline int g_gemm_waves = 4;              // tunable: GPC_GEMM_WAVES (4 or 8) for 128-tiles
 template <typename T>
-inline hipError_t launch_gemm(hipStream_t st, GemmArgs g, bool akm, bool bkm, int batch, int force_bt = 0) {
+inline hipError_t launch_gemm(hipStream_t st, GemmArgs g, bool akm, bool bkm, int batch, int force_bt = 0,
+                             int* ctr = nullptr) {
   const int tm = g.M / TILE, tn = g.N / TILE;
   const long long blocks128 = (long long)(g.lower_only ? tm * (tm + 1) / 2 : tm * tn) * batch;
   const bool small = force_bt ? (force_bt == 64) : (blocks128 < g_small_launch_blocks);
   if (small) return launch_gemm_bt<T, 64, 4>(st, g, akm, bkm, batch);
   if (g_gemm_waves == 8) return launch_gemm_bt<T, 128, 8>(st, g, akm, bkm, batch);
-  return launch_gemm_bt<T, 128, 4>(st, g, akm, bkm, batch);
+  return launch_gemm_bt<T, 128, 4>(st, g, akm, bkm, batch, ctr);
 }
 
 // algorithmic flops of one launch (for the roofline bookkeeping)

@@ -168,6 +168,8 @@ struct gpc_ctx {
   DevBuf ks, vb, kss, xss, pout; // predict / predict_full / quad
   DevBuf dbg1, dbg2, dbg3;       // debug hooks / fetch staging
   PinBuf pin;                    // pinned staging for host<->device transfers (see PinBuf)
+  DevBuf tile_ctr;               // counters of the persistent GEMM launches, CTR_PER_GROUP per sample group
+  static constexpr int CTR_PER_GROUP = 256;
   // Freed posterior storage, kept for the next gpc_posterior_batch: hipMalloc/hipFree of the
   // multi-GB S x npad^2 factors cost more than computing them (update() in a fit / active-learning
   // loop creates a new posterior set and drops the previous one every iteration).
@@ -430,6 +432,11 @@ struct Pipe {
       F.ev_fork = c->ev_fork[gidx];
       F.ev_join = c->ev_join[gidx];
       F.defer_min = c->defer_min;
+    }
+    if (gpc::g_persist_spare >= 0) {
+      F.ctr = c->tile_ctr.as<int>() + (size_t)gidx * gpc_ctx::CTR_PER_GROUP;
+      F.ctr_cap = gpc_ctx::CTR_PER_GROUP;
+      HIPCHK(c, hipMemsetAsync(F.ctr, 0, gpc_ctx::CTR_PER_GROUP * sizeof(int), st));
     }
     // NLL only: the inverse of the whole matrix is not needed (only of left children)
     const bool full_inv = (mode != MODE_NLL);
@@ -1261,7 +1268,7 @@ int gpc_create(int device, gpc_ctx** out) {
   }
   gpc_ctx* c = new gpc_ctx();
   c->device = device;
-  hipDeviceProp_t prop;
+  hipDeviceProp_t prop{};
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
     char buf[512];
     snprintf(buf, sizeof buf, "%s arch=%s CUs=%d clock=%dMHz mem=%.1fGB lds/block=%zuKB", prop.name,
@@ -1299,6 +1306,13 @@ int gpc_create(int device, gpc_ctx** out) {
     delete c;
     return -1;
   }
+  if (const char* e = getenv("GPC_PERSIST_SPARE")) gpc::g_persist_spare = atoi(e);  // < 0: no persistent launches
+  gpc::g_block_slots = 2 * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+  if (c->tile_ctr.ensure((gpc_ctx::MAXG + 1) * gpc_ctx::CTR_PER_GROUP * sizeof(int)) != hipSuccess) {
+    g_create_err = "allocating the tile counters failed";
+    delete c;
+    return -1;
+  }
   if (const char* e = getenv("GPC_GROUPS")) c->groups = std::max(1, std::min((int)gpc_ctx::MAXG, atoi(e)));
   if (const char* e = getenv("GPC_SMALL_BLOCKS")) gpc::g_small_launch_blocks = atoi(e);
   if (const char* e = getenv("GPC_GEMM_FLAGS")) gpc::g_gemm_flags = atoi(e);
@@ -1319,7 +1333,7 @@ void gpc_destroy(gpc_ctx* c) {
   DevBuf* bufs[] = {&c->dX,   &c->mA,    &c->mW,  &c->mT,   &c->xs,   &c->spb,  &c->mulb, &c->divb,
                     &c->dvec, &c->rvec,  &c->zvec, &c->avec, &c->scal, &c->parts, &c->gout, &c->diagq,
                     &c->dmb,  &c->dsn2b, &c->mg,  &c->ng,   &c->ks,   &c->vb,   &c->xss,  &c->pout, &c->kss,
-                    &c->dbg1, &c->dbg2,  &c->dbg3, &c->tpart};
+                    &c->dbg1, &c->dbg2,  &c->dbg3, &c->tpart, &c->tile_ctr};
   for (DevBuf* b : bufs) b->release();
   c->pool_drain();
   c->pin.release();
@@ -1668,8 +1682,9 @@ int gpc_mfma_peak(gpc_ctx* c, int dtype, double* tflops, double* cycles_per_mfma
       HIPCHK(c, hipMemcpy(hclk, d_clk, sizeof hclk, hipMemcpyDeviceToHost));
       if (tf > best) {
         best = tf;
-        best_cyc = (double)hclk[0] / ((double)iters * nacc) / wps;  // per MFMA per SIMD
         best_ghz = hclk[1] > 0 ? (double)hclk[0] / ((double)hclk[1] * 10.0) : 0.0;
+        // issue interval of one SIMD, from the aggregate rate and the measured shader clock
+        best_cyc = best_ghz * 1e9 * (4.0 * prop.multiProcessorCount) * (2.0 * 16 * 16 * 4) / (tf * 1e12);
       }
     }
   *tflops = best;

@@ -46,6 +46,9 @@ struct Factor {
   hipEvent_t* ev_fork = nullptr;   // [MAX_DEPTH]
   hipEvent_t* ev_join = nullptr;   // [MAX_DEPTH]
   int defer_min = 512;             // smallest node (n) whose 5a is deferred
+  // zeroed device counters for persistent GEMM launches (gemm.h); one per launch, in order
+  int* ctr = nullptr;
+  int ctr_cap = 0, ctr_used = 0;
   double flops = 0;      // algorithmic flops issued (tile-exact)
   int launches = 0;
   hipError_t err = hipSuccess;
@@ -74,7 +77,8 @@ struct Factor {
     g.tiles_n = N / TILE;
     flops += gemm_flops(g, batch);
     ++launches;
-    hipError_t e = launch_gemm<T>(on ? on : st, g, akm, bkm, batch);
+    int* slot = (ctr && ctr_used < ctr_cap) ? ctr + ctr_used++ : nullptr;
+    hipError_t e = launch_gemm<T>(on ? on : st, g, akm, bkm, batch, 0, slot);
     if (e != hipSuccess && err == hipSuccess) err = e;
   }
 
