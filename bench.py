@@ -169,7 +169,7 @@ def main():
             assert gathered.shape == (world * S, 1 + (hyp_N if grad else 0))
 
     # The dominant single kernel, timed alone: two extra UNTIMED steps with one sample group, so
-    # the W^T W launch (gemm_kernel<T,true,true,128,4>, all S samples in one grid) is not
+    # the W^T W launch (gemm_persist_kernel<T,true,true,128,4>, all S samples in one grid) is not
     # co-scheduled with another group's kernels and its hipEvent time is the kernel's duration.
     lau_ms, lau_fl = [], 0.0
     if rank == 0 and grad:
@@ -192,6 +192,11 @@ def main():
         from gpyreg_amd import _lib as L_
 
         tf, cyc, ghz = ctx.mfma_peak(L_.F64 if dtype == "f64" else L_.F32)
+        traffic = {}
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01g_traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as fh:
+                traffic = json.load(fh)
         out = {
             "metric": "GP-fits/sec (NLL+grad, N=4096 D=10)" if (args.config == 3 and grad)
             else f"GP {'fits' if grad else 'NLL evals'}/sec (N={N} D={cfg['D']})",
@@ -220,19 +225,23 @@ def main():
                 "peak": peak,
                 "unit": "TFLOP/s",
                 "frac": achieved / peak,
-                "traffic": None,
+                # memory-side bytes per step from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled,
+                # + WRITE_SIZE; profiles/r01g_pmc_summary.txt); PMC cannot be collected inside a timed run
+                "traffic": traffic.get("step_traffic_bytes") if (args.config == 3 and grad and dtype == "f64") else None,
+                "traffic_source": traffic.get("source") if (args.config == 3 and grad and dtype == "f64") else None,
                 "flops_per_launch": flops_per_launch,
                 "launch_ms": fac * 1e3,
                 "device_ms_per_step": float(np.mean(tot_ms)),
                 "measured_mfma_ceiling": {"tflops": tf, "cycles_per_mfma_per_simd": cyc, "clock_ghz": ghz},
                 # the single dominant kernel (one launch per sample group): W^T W ("lauum"),
-                # gemm_kernel<T,true,true,128,4> in the rocprofv3 summary under profiles/
+                # gemm_persist_kernel<T,true,true,128,4> in the rocprofv3 summary under profiles/
                 "dominant_kernel": None if not (grad and lau_fl > 0) else {
-                    "name": "gemm_kernel<T,true,true,128,4> (lauum: (K+sn2 I)^-1 = W^T W), all samples in one launch",
+                    "name": "gemm_persist_kernel<T,true,true,128,4> (lauum: (K+sn2 I)^-1 = W^T W), all samples in one persistent launch",
                     "flops_per_launch": lau_fl,
                     "launch_ms": float(np.mean(lau_ms)),
                     "achieved": lau_fl / (float(np.mean(lau_ms)) * 1e-3) / 1e12,
                     "frac": lau_fl / (float(np.mean(lau_ms)) * 1e-3) / 1e12 / peak,
+                    "traffic": traffic.get("dominant_kernel_traffic_bytes") if (args.config == 3 and dtype == "f64") else None,
                 },
             },
             "nlz_sample0": float(nlz[0]),
