@@ -336,7 +336,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_persist_kernel(GemmArgs 
 }
 
 inline int g_gemm_pad_lds = 0;  // experiment: extra dynamic LDS (bytes) on 128-tile launches
-inline int g_persist_spare = 16;    // tunable: GPC_PERSIST_SPARE (block slots a persistent launch leaves free)
+inline int g_persist_spare = 0;     // tunable: GPC_PERSIST_SPARE (block slots a persistent launch leaves free)
 inline int g_block_slots = 512;     // two 128-tile blocks per CU (set from the device's CU count)
 template <typename T, int BT, int NW>
 inline hipError_t launch_gemm_bt(hipStream_t st, GemmArgs g, bool akm, bool bkm, int batch, int* ctr = nullptr) {

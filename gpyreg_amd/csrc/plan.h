@@ -88,7 +88,11 @@ struct Factor {
 
   void potrf_inv(int off, int n, bool need_inv, bool keep_L, int depth = 0) {
     if (n == TILE) {
-      if (g_leaf_version == 2)
+      if (g_leaf_version == 3)
+        hipLaunchKernelGGL((leaf3_kernel<T>), dim3(batch), dim3(256), 0, st, blk(A, off, off), sA, npad,
+                           blk(W, off, off), sW, npad, off, logdet, info,
+                           std::max(0, std::min(TILE, nvalid - off)));
+      else if (g_leaf_version == 2)
         hipLaunchKernelGGL((leaf2_kernel<T>), dim3(batch), dim3(256), 0, st, blk(A, off, off), sA, npad,
                            blk(W, off, off), sW, npad, off, logdet, info,
                            std::max(0, std::min(TILE, nvalid - off)));
