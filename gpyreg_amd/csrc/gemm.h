@@ -49,11 +49,11 @@ struct GemmArgs {
   int beta;  // 0 or 1
   int klo, khi, lower_only;
   int tiles_m, tiles_n;
-  int flags;  // reserved for experiment switches (GPC_GEMM_FLAGS); unused by the kernel
+  int flags;  // GPC_GEMM_FLAGS: 8 = XCD-affine tile queues in persistent launches
   int* ctr;    // persistent launches: zeroed device counter the blocks draw tiles from
   int ntiles, batch;
 };
-inline int g_gemm_flags = 0;
+inline int g_gemm_flags = 8;  // bit 3: XCD-affine tile queues in persistent launches
 
 // Staging addresses are split into a block-uniform pointer `u` (tile origin, advanced by the
 // caller one k-slab at a time: scalar adds only) and a per-thread element offset fixed for the
@@ -320,18 +320,44 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(GemmArgs g) {
 // GEMM block instead of two: room (registers, LDS) for the leaf / deep-level launches of the
 // other sample group, which otherwise wait for this whole launch to drain
 // (profiles/r01g_coresidency_probe.txt).
+// XCD affinity (default; GPC_XCD_AFFINE=0 clears g.flags & 8): the (tile, sample) pairs are split into 8 queues by sample index
+// and a block serves the queue of the XCD it runs on first (HW_REG_XCC_ID), stealing from the
+// others when its own is empty.  Blocks that share an L2 then work on tiles of the same one
+// or two samples, consecutive tiles of a sample share an operand panel, and the panel is read
+// from HBM / Infinity Cache once per XCD instead of once per tile.
+constexpr int NQ = 8;
 template <typename T, bool AKM, bool BKM, int BT, int NW>
 __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_persist_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) T smem[4 * opsz_of(BT)];
   __shared__ int next_tile;
-  const int total = g.ntiles * g.batch;
-  for (;;) {
-    if (threadIdx.x == 0) next_tile = atomicAdd(g.ctr, 1);
-    __syncthreads();
-    const int idx = __builtin_amdgcn_readfirstlane(next_tile);
-    __syncthreads();  // everyone holds idx before thread 0 may overwrite it; also fences the LDS stages
-    if (idx >= total) break;
-    gemm_tile<T, AKM, BKM, BT, NW>(g, idx / g.batch, idx % g.batch, smem);
+  if (!(g.flags & 8)) {
+    const int total = g.ntiles * g.batch;
+    for (;;) {
+      if (threadIdx.x == 0) next_tile = atomicAdd(g.ctr, 1);
+      __syncthreads();
+      const int idx = __builtin_amdgcn_readfirstlane(next_tile);
+      __syncthreads();  // everyone holds idx before thread 0 may overwrite it; also fences the LDS stages
+      if (idx >= total) break;
+      gemm_tile<T, AKM, BKM, BT, NW>(g, idx / g.batch, idx % g.batch, smem);
+    }
+    return;
+  }
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  const int q0 = (int)(xcc & (NQ - 1));
+  for (int a = 0; a < NQ; ++a) {
+    const int q = (q0 + a) & (NQ - 1);
+    const int nsq = (g.batch - q + NQ - 1) / NQ;  // samples q, q + 8, ... of this queue
+    const int total = g.ntiles * nsq;
+    if (nsq <= 0) continue;
+    for (;;) {
+      if (threadIdx.x == 0) next_tile = atomicAdd(g.ctr + q, 1);
+      __syncthreads();
+      const int idx = __builtin_amdgcn_readfirstlane(next_tile);
+      __syncthreads();
+      if (idx >= total) break;
+      gemm_tile<T, AKM, BKM, BT, NW>(g, idx / nsq, q + NQ * (idx % nsq), smem);
+    }
   }
 }
 

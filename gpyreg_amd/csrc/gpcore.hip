@@ -169,7 +169,7 @@ struct gpc_ctx {
   DevBuf dbg1, dbg2, dbg3;       // debug hooks / fetch staging
   PinBuf pin;                    // pinned staging for host<->device transfers (see PinBuf)
   DevBuf tile_ctr;               // counters of the persistent GEMM launches, CTR_PER_GROUP per sample group
-  static constexpr int CTR_PER_GROUP = 256;
+  static constexpr int CTR_PER_GROUP = 1024;
   // Freed posterior storage, kept for the next gpc_posterior_batch: hipMalloc/hipFree of the
   // multi-GB S x npad^2 factors cost more than computing them (update() in a fit / active-learning
   // loop creates a new posterior set and drops the previous one every iteration).
@@ -1316,6 +1316,7 @@ int gpc_create(int device, gpc_ctx** out) {
   if (const char* e = getenv("GPC_GROUPS")) c->groups = std::max(1, std::min((int)gpc_ctx::MAXG, atoi(e)));
   if (const char* e = getenv("GPC_SMALL_BLOCKS")) gpc::g_small_launch_blocks = atoi(e);
   if (const char* e = getenv("GPC_GEMM_FLAGS")) gpc::g_gemm_flags = atoi(e);
+  if (const char* e = getenv("GPC_XCD_AFFINE")) gpc::g_gemm_flags = atoi(e) ? (gpc::g_gemm_flags | 8) : (gpc::g_gemm_flags & ~8);
   if (const char* e = getenv("GPC_LEAF")) gpc::g_leaf_version = atoi(e);
   if (const char* e = getenv("GPC_GEMM_WAVES")) gpc::g_gemm_waves = atoi(e);
   if (const char* e = getenv("GPC_GEMM_PADLDS")) gpc::g_gemm_pad_lds = atoi(e);

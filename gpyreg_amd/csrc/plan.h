@@ -77,7 +77,11 @@ struct Factor {
     g.tiles_n = N / TILE;
     flops += gemm_flops(g, batch);
     ++launches;
-    int* slot = (ctr && ctr_used < ctr_cap) ? ctr + ctr_used++ : nullptr;
+    int* slot = nullptr;  // NQ counters per persistent launch
+    if (ctr && ctr_used + NQ <= ctr_cap) {
+      slot = ctr + ctr_used;
+      ctr_used += NQ;
+    }
     hipError_t e = launch_gemm<T>(on ? on : st, g, akm, bkm, batch, 0, slot);
     if (e != hipSuccess && err == hipSuccess) err = e;
   }

@@ -85,7 +85,7 @@ def _spd(n, rng, noise=0.01, D=2):
     return np.exp(-0.5 * d / D) / noise + np.eye(n)
 
 
-@pytest.mark.parametrize("n", [128, 7, 33, 129, 256, 300, 640])
+@pytest.mark.parametrize("n", [128, 7, 16, 17, 33, 100, 112, 113, 129, 256, 300, 640])
 def test_factor_inverse_fp64(ctx, n):
     rng = np.random.default_rng(n)
     A = _spd(n, rng)
