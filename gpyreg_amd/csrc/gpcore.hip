@@ -140,17 +140,11 @@ struct gpc_ctx {
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   static constexpr int MAXG = 8;
   hipStream_t gst[MAXG] = {};  // sample-group streams
-  hipEvent_t ev_up = nullptr, ev_done[MAXG] = {}, ev_half[MAXG] = {};
+  hipEvent_t ev_up = nullptr, ev_done[MAXG] = {};
   int groups = 2;
-  int stagger = 0;  // group g starts when group g-1 has factored its left half
-  // side streams for the deferred trtri products (plan.h), per group and recursion depth
-  static constexpr int MAXD = 8;
-  hipStream_t sst[MAXG + 1][MAXD] = {};
-  hipEvent_t ev_fork[MAXG + 1][MAXD] = {}, ev_join[MAXG + 1][MAXD] = {};
   hipEvent_t ev_l0[MAXG + 1] = {}, ev_l1[MAXG + 1] = {};  // around the lauum launch of each group
   double ms_lauum = 0, flops_lauum = 0;  // slowest group's lauum launch of the last call
   int lauum_groups = 0;
-  int defer = 0, defer_min = 512;  // measured slower on MI355X/ROCm 7.2
   std::string err;
   std::string devinfo;
   // resident training data
@@ -388,8 +382,7 @@ struct Pipe {
 
   // Device kernels for `n` samples of the current chunk starting at chunk index `off`
   // (all per-sample buffers are indexed by chunk position), issued on stream `st`.
-  int device_section(hipStream_t st, int off, int n, hipEvent_t f0, hipEvent_t f1, hipEvent_t half = nullptr,
-                     int gidx = gpc_ctx::MAXG) {
+  int device_section(hipStream_t st, int off, int n, hipEvent_t f0, hipEvent_t f1, int gidx = gpc_ctx::MAXG) {
     Batch& b = *B;
     const int npad = b.npad, N = b.N, D = b.D;
     T* Ac = A + (size_t)off * sM;
@@ -426,13 +419,6 @@ struct Pipe {
     F.logdet = d_logdet;
     F.info = d_info;
     F.nvalid = N;
-    F.half_event = half;
-    if (c->defer && npad >= 2 * c->defer_min) {
-      F.side = c->sst[gidx];
-      F.ev_fork = c->ev_fork[gidx];
-      F.ev_join = c->ev_join[gidx];
-      F.defer_min = c->defer_min;
-    }
     if (gpc::g_persist_spare >= 0) {
       F.ctr = c->tile_ctr.as<int>() + (size_t)gidx * gpc_ctx::CTR_PER_GROUP;
       F.ctr_cap = gpc_ctx::CTR_PER_GROUP;
@@ -569,9 +555,7 @@ struct Pipe {
         const int lo = (int)((long long)cnt * g / groups), hi = (int)((long long)cnt * (g + 1) / groups);
         hipStream_t sg = c->gst[g];
         HIPCHK(c, hipStreamWaitEvent(sg, c->ev_up, 0));
-        if (c->stagger && g > 0) HIPCHK(c, hipStreamWaitEvent(sg, c->ev_half[g - 1], 0));
-        int rc = device_section(sg, lo, hi - lo, g == 0 ? c->ev[1] : nullptr, nullptr,
-                                c->stagger ? c->ev_half[g] : nullptr, g);
+        int rc = device_section(sg, lo, hi - lo, g == 0 ? c->ev[1] : nullptr, nullptr, g);
         if (rc) return rc;
         HIPCHK(c, hipEventRecord(c->ev_done[g], sg));
         HIPCHK(c, hipStreamWaitEvent(st, c->ev_done[g], 0));
@@ -1292,15 +1276,9 @@ int gpc_create(int device, gpc_ctx** out) {
   bool ok = hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming) == hipSuccess;
   for (int g = 0; g <= gpc_ctx::MAXG && ok; ++g)
     ok = hipEventCreate(&c->ev_l0[g]) == hipSuccess && hipEventCreate(&c->ev_l1[g]) == hipSuccess;
-  for (int g = 0; g <= gpc_ctx::MAXG && ok; ++g)
-    for (int d = 0; d < gpc_ctx::MAXD && ok; ++d)
-      ok = hipStreamCreateWithPriority(&c->sst[g][d], hipStreamNonBlocking, prio_lo) == hipSuccess &&
-           hipEventCreateWithFlags(&c->ev_fork[g][d], hipEventDisableTiming) == hipSuccess &&
-           hipEventCreateWithFlags(&c->ev_join[g][d], hipEventDisableTiming) == hipSuccess;
   for (int g = 0; g < gpc_ctx::MAXG && ok; ++g)
     ok = hipStreamCreateWithPriority(&c->gst[g], hipStreamNonBlocking, prio_hi) == hipSuccess &&
-         hipEventCreateWithFlags(&c->ev_done[g], hipEventDisableTiming) == hipSuccess &&
-         hipEventCreateWithFlags(&c->ev_half[g], hipEventDisableTiming) == hipSuccess;
+         hipEventCreateWithFlags(&c->ev_done[g], hipEventDisableTiming) == hipSuccess;
   if (!ok) {
     g_create_err = "creating the sample-group streams failed";
     delete c;
@@ -1320,9 +1298,6 @@ int gpc_create(int device, gpc_ctx** out) {
   if (const char* e = getenv("GPC_LEAF")) gpc::g_leaf_version = atoi(e);
   if (const char* e = getenv("GPC_GEMM_WAVES")) gpc::g_gemm_waves = atoi(e);
   if (const char* e = getenv("GPC_GEMM_PADLDS")) gpc::g_gemm_pad_lds = atoi(e);
-  if (const char* e = getenv("GPC_DEFER")) c->defer = atoi(e);
-  if (const char* e = getenv("GPC_DEFER_MIN")) c->defer_min = atoi(e);
-  if (const char* e = getenv("GPC_STAGGER")) c->stagger = atoi(e);
   *out = c;
   return 0;
 }
@@ -1345,15 +1320,8 @@ void gpc_destroy(gpc_ctx* c) {
     if (c->ev_l0[g]) (void)hipEventDestroy(c->ev_l0[g]);
     if (c->ev_l1[g]) (void)hipEventDestroy(c->ev_l1[g]);
   }
-  for (int g = 0; g <= gpc_ctx::MAXG; ++g)
-    for (int d = 0; d < gpc_ctx::MAXD; ++d) {
-      if (c->ev_fork[g][d]) (void)hipEventDestroy(c->ev_fork[g][d]);
-      if (c->ev_join[g][d]) (void)hipEventDestroy(c->ev_join[g][d]);
-      if (c->sst[g][d]) (void)hipStreamDestroy(c->sst[g][d]);
-    }
   for (int g = 0; g < gpc_ctx::MAXG; ++g) {
     if (c->ev_done[g]) (void)hipEventDestroy(c->ev_done[g]);
-    if (c->ev_half[g]) (void)hipEventDestroy(c->ev_half[g]);
     if (c->gst[g]) (void)hipStreamDestroy(c->gst[g]);
   }
   if (c->st) (void)hipStreamDestroy(c->st);

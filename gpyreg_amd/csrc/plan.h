@@ -35,17 +35,6 @@ struct Factor {
   long long sA, sW, sT;  // batch strides (elements)
   double* logdet;        // [batch], must be zeroed by the caller
   int* info;             // [batch], must be zeroed by the caller
-  hipEvent_t half_event = nullptr;  // recorded once the left half of the whole matrix is factored
-  // Off-critical-path work: U = L21 * W11 (step 5a) does not depend on the right child's
-  // factorization, so it is forked onto a low-priority side stream (one per recursion depth;
-  // at most one product is outstanding per depth) and joined before step 5b.  The critical
-  // path (leaves, deep levels) is latency bound and leaves most CUs idle; the deferred
-  // products fill them.
-  static constexpr int MAX_DEPTH = 8;
-  hipStream_t* side = nullptr;     // [MAX_DEPTH] or null
-  hipEvent_t* ev_fork = nullptr;   // [MAX_DEPTH]
-  hipEvent_t* ev_join = nullptr;   // [MAX_DEPTH]
-  int defer_min = 512;             // smallest node (n) whose 5a is deferred
   // zeroed device counters for persistent GEMM launches (gemm.h); one per launch, in order
   int* ctr = nullptr;
   int ctr_cap = 0, ctr_used = 0;
@@ -90,7 +79,7 @@ struct Factor {
     if (e != hipSuccess && err == hipSuccess) err = e;
   }
 
-  void potrf_inv(int off, int n, bool need_inv, bool keep_L, int depth = 0) {
+  void potrf_inv(int off, int n, bool need_inv, bool keep_L) {
     if (n == TILE) {
       if (g_leaf_version == 3)
         hipLaunchKernelGGL((leaf3_kernel<T>), dim3(batch), dim3(256), 0, st, blk(A, off, off), sA, npad,
@@ -110,32 +99,18 @@ struct Factor {
     const int q = n / TILE;
     const int n1 = (q / 2) * TILE, n2 = n - n1;
     const int o1 = off, o2 = off + n1;
-    potrf_inv(o1, n1, true, keep_L, depth + 1);
-    if (half_event && off == 0 && n == npad) (void)hipEventRecord(half_event, st);
+    potrf_inv(o1, n1, true, keep_L);
     // 2. T21 = A21 * W11^T
     gemm(blk(Tm, o2, o1), sT, blk(A, o2, o1), sA, blk(W, o1, o1), sW, n2, n1, n1, false, false, 1.0,
          0, KLO_ZERO, KHI_COL, 0);
     // 3. A22 -= T21 * T21^T
     gemm(blk(A, o2, o2), sA, blk(Tm, o2, o1), sT, blk(Tm, o2, o1), sT, n2, n2, n1, false, false, -1.0,
          1, KLO_ZERO, KHI_FULL, 1);
-    const bool defer = need_inv && side && depth < MAX_DEPTH && n >= defer_min;
-    if (defer) {
-      // 5a forked: U = T21 * W11 -> A21 (reads what steps 1-2 produced, writes a block the
-      // right child never touches)
-      chk(hipEventRecord(ev_fork[depth], st));
-      chk(hipStreamWaitEvent(side[depth], ev_fork[depth], 0));
-      gemm(blk(A, o2, o1), sA, blk(Tm, o2, o1), sT, blk(W, o1, o1), sW, n2, n1, n1, false, true, 1.0,
-           0, KLO_COL, KHI_FULL, 0, side[depth]);
-      chk(hipEventRecord(ev_join[depth], side[depth]));
-    }
-    potrf_inv(o2, n2, need_inv, keep_L, depth + 1);
+    potrf_inv(o2, n2, need_inv, keep_L);
     if (need_inv) {
       // 5a. U = T21 * W11  -> A21
-      if (defer)
-        chk(hipStreamWaitEvent(st, ev_join[depth], 0));
-      else
-        gemm(blk(A, o2, o1), sA, blk(Tm, o2, o1), sT, blk(W, o1, o1), sW, n2, n1, n1, false, true, 1.0,
-             0, KLO_COL, KHI_FULL, 0);
+      gemm(blk(A, o2, o1), sA, blk(Tm, o2, o1), sT, blk(W, o1, o1), sW, n2, n1, n1, false, true, 1.0, 0,
+           KLO_COL, KHI_FULL, 0);
       // 5b. W21 = -W22 * U
       gemm(blk(W, o2, o1), sW, blk(W, o2, o2), sW, blk(A, o2, o1), sA, n2, n1, n2, false, true, -1.0,
            0, KLO_ZERO, KHI_ROW, 0);

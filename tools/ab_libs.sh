@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of prebuilt library variants: bash tools_ab_libs.sh <lib1.so> <lib2.so> ...   (each is copied over gpyreg_amd/lib/libgpcore.so)
+# A/B of prebuilt library variants: bash tools/ab_libs.sh <lib1.so> <lib2.so> ...   (each is copied over gpyreg_amd/lib/libgpcore.so)
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
 cp gpyreg_amd/lib/libgpcore.so /tmp/libgpcore_base.so
 for lib in base "$@"; do

@@ -1,4 +1,6 @@
 """throughput of the batched design evaluation (fit's f_min_fill stage): S NLL evaluations at once."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import time
 import numpy as np
 import bench

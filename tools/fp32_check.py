@@ -1,4 +1,6 @@
 """fp32-vs-fp64 accuracy of NLL and gradient on the bench workloads (GPU box)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sys, time
 import numpy as np
 import bench

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): bash tools_gpu_run.sh <tag> [steps]
+# usage (on the GPU box, from the repo root): bash tools/gpu_run.sh <tag> [steps]
 # runs: GPU tests -> smoke -> bench -> rocprofv3 kernel trace of the bench; logs under gpurun_out/<tag>/
 set -o pipefail
 TAG=${1:-run}; STEPS=${2:-5}

@@ -1,4 +1,6 @@
 """where does the wall time of nll_batch calls go? (GPC_HOSTTIME phases + wall clock)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import os, sys, time
 import numpy as np
 import bench

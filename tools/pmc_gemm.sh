@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC passes focused on the LDS/MFMA interplay of the lauum GEMM; bash tools_pmc_gemm.sh <tag> [flags...]
+# PMC passes focused on the LDS/MFMA interplay of the lauum GEMM; bash tools/pmc_gemm.sh <tag> [flags...]
 R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=$1; shift; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 export GPC_GROUPS=1

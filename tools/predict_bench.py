@@ -1,4 +1,6 @@
 """posterior + predict throughput on the bench workloads (GPU box)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import time
 import numpy as np
 import bench

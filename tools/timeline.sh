@@ -1,5 +1,5 @@
 #!/bin/bash
-# bash tools_timeline.sh <tag> [env assignments...]  -> compact per-launch timeline of the last bench step
+# bash tools/timeline.sh <tag> [env assignments...]  -> compact per-launch timeline of the last bench step
 R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=$1; shift; O=$R/gpurun_out/$TAG; mkdir -p $O
 for kv in "$@"; do export "$kv"; done
 cd /tmp && export TMPDIR=/tmp

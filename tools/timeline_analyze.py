@@ -1,4 +1,4 @@
-"""summarise a tools_timeline.sh trace: per step, kernel-class busy time, union busy time, idle gaps."""
+"""summarise a tools/timeline.sh trace: per step, kernel-class busy time, union busy time, idle gaps."""
 import gzip, sys, collections
 rows = []
 for line in gzip.open(sys.argv[1], "rt"):

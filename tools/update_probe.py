@@ -1,4 +1,6 @@
 """repeated GP.update (posterior sets) wall time with host phase breakdown."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import os, sys, time
 import numpy as np
 import bench
