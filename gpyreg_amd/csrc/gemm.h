@@ -49,9 +49,9 @@ struct GemmArgs {
   int beta;  // 0 or 1
   int klo, khi, lower_only;
   int tiles_m, tiles_n;
-  int flags;  // GPC_GEMM_FLAGS: 8 = XCD-affine tile queues in persistent launches
-  int* ctr;    // persistent launches: zeroed device counter the blocks draw tiles from
-  int ntiles, batch;
+  int flags = 0;       // GPC_GEMM_FLAGS: 8 = XCD-affine tile queues in persistent launches
+  int* ctr = nullptr;  // persistent launches: zeroed device counters the blocks draw tiles from
+  int ntiles = 0, batch = 0;
 };
 inline int g_gemm_flags = 8;  // bit 3: XCD-affine tile queues in persistent launches
 
@@ -79,14 +79,28 @@ __device__ __forceinline__ size_t stage_pstride(int ld) {
   else
     return (size_t)(NT / (BT / VEC)) * ld;
 }
+// One staging pass of an operand: NV 16-byte vectors per thread through raw buffer loads
+// (buffer_load_dwordx4 v, voffset, s[rsrc], soffset offen): the descriptor's base is the tile
+// origin, the per-thread byte offset `voff` is fixed for the whole k-loop and the slab / pass
+// offsets are scalars, so the loop carries no vector address arithmetic at all
+// (241 instead of 256 VGPRs in the fp64 128-tile kernel).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
 template <typename T, bool KM, int BT, int NT>
 __device__ __forceinline__ void g2r(typename MM<T>::vec_t (&r)[(BT * BKT) / (NT * MM<T>::VEC)],
-                                    const T* __restrict__ u, size_t pstride, unsigned toff) {
+                                    __amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned pstride_bytes,
+                                    unsigned voff) {
   using vec_t = typename MM<T>::vec_t;
   constexpr int NV = (BT * BKT) / (NT * MM<T>::VEC);
+  static_assert(sizeof(vec_t) == 16, "16-byte staging vectors");
   static_assert(KM ? (NT % (BT / MM<T>::VEC) == 0) : (NT % (BKT / MM<T>::VEC) == 0), "pass layout");
 #pragma unroll
-  for (int p = 0; p < NV; ++p) r[p] = *reinterpret_cast<const vec_t*>(u + p * pstride + toff);
+  for (int p = 0; p < NV; ++p) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff + p * pstride_bytes, 0);
+    r[p] = *reinterpret_cast<const vec_t*>(&v);
+  }
 }
 
 template <typename T, bool KM, int BT, int NT>
@@ -192,20 +206,26 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
 
   if (nk > 0) {
     vec_t ra[NV], rb[NV];
-    const unsigned toa = stage_toff<T, AKM, BT, NT>(g.lda, t), tob = stage_toff<T, BKM, BT, NT>(g.ldb, t);
-    const size_t psa = stage_pstride<T, AKM, BT, NT>(g.lda), psb = stage_pstride<T, BKM, BT, NT>(g.ldb);
-    const size_t stepa = AKM ? (size_t)BKT * g.lda : (size_t)BKT, stepb = BKM ? (size_t)BKT * g.ldb : (size_t)BKT;
-    const T* ua = AKM ? A + (size_t)k0 * g.lda + m0 : A + (size_t)m0 * g.lda + k0;
-    const T* ub = BKM ? B + (size_t)k0 * g.ldb + n0 : B + (size_t)n0 * g.ldb + k0;
-    g2r<T, AKM, BT, NT>(ra, ua, psa, toa);
-    g2r<T, BKM, BT, NT>(rb, ub, psb, tob);
+    // byte offsets: per thread (fixed), per pass and per slab (block-uniform); an operand of one
+    // sample is < 4 GB for every supported size (N <= 16384 fp64)
+    const unsigned toa = stage_toff<T, AKM, BT, NT>(g.lda, t) * (unsigned)sizeof(T),
+                   tob = stage_toff<T, BKM, BT, NT>(g.ldb, t) * (unsigned)sizeof(T);
+    const unsigned psa = (unsigned)(stage_pstride<T, AKM, BT, NT>(g.lda) * sizeof(T)),
+                   psb = (unsigned)(stage_pstride<T, BKM, BT, NT>(g.ldb) * sizeof(T));
+    const unsigned stepa = (unsigned)((AKM ? (size_t)BKT * g.lda : (size_t)BKT) * sizeof(T)),
+                   stepb = (unsigned)((BKM ? (size_t)BKT * g.ldb : (size_t)BKT) * sizeof(T));
+    const __amdgpu_buffer_rsrc_t rsa = make_rsrc(AKM ? A + (size_t)k0 * g.lda + m0 : A + (size_t)m0 * g.lda + k0);
+    const __amdgpu_buffer_rsrc_t rsb = make_rsrc(BKM ? B + (size_t)k0 * g.ldb + n0 : B + (size_t)n0 * g.ldb + k0);
+    unsigned ua = 0, ub = 0;  // slab offsets
+    g2r<T, AKM, BT, NT>(ra, rsa, ua, psa, toa);
+    g2r<T, BKM, BT, NT>(rb, rsb, ub, psb, tob);
     r2s<T, AKM, BT, NT>(smem, ra, t);
     r2s<T, BKM, BT, NT>(smem + OPSZ, rb, t);
     // slab 1 is in flight while slab 0 is multiplied (nk is a multiple of 8)
     ua += stepa;
     ub += stepb;
-    g2r<T, AKM, BT, NT>(ra, ua, psa, toa);
-    g2r<T, BKM, BT, NT>(rb, ub, psb, tob);
+    g2r<T, AKM, BT, NT>(ra, rsa, ua, psa, toa);
+    g2r<T, BKM, BT, NT>(rb, rsb, ub, psb, tob);
     __syncthreads();
 
     // Software pipeline of one k-slab (4 k-steps of MRM x MRN MFMAs) out of LDS stage CUR.
@@ -266,8 +286,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
       if constexpr (LD) {
         ua += stepa;
         ub += stepb;
-        g2r<T, AKM, BT, NT>(ra, ua, psa, toa);
-        g2r<T, BKM, BT, NT>(rb, ub, psb, tob);
+        g2r<T, AKM, BT, NT>(ra, rsa, ua, psa, toa);
+        g2r<T, BKM, BT, NT>(rb, rsb, ub, psb, tob);
       }
       if constexpr (WR) load_frags(0, a_n, a_n + OPSZ, 0);
       mfmas(1);
