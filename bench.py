@@ -193,9 +193,10 @@ def main():
 
         tf, cyc, ghz = ctx.mfma_peak(L_.F64 if dtype == "f64" else L_.F32)
         traffic = {}
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01g_traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as fh:
+        import glob
+        tfiles = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_traffic.json")))
+        if tfiles:  # the most recent committed PMC measurement
+            with open(tfiles[-1]) as fh:
                 traffic = json.load(fh)
         out = {
             "metric": "GP-fits/sec (NLL+grad, N=4096 D=10)" if (args.config == 3 and grad)
@@ -226,7 +227,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved / peak,
                 # memory-side bytes per step from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled,
-                # + WRITE_SIZE; profiles/r01g_pmc_summary.txt); PMC cannot be collected inside a timed run
+                # + WRITE_SIZE; profiles/r*_pmc_summary.txt); PMC cannot be collected inside a timed run
                 "traffic": traffic.get("step_traffic_bytes") if (args.config == 3 and grad and dtype == "f64") else None,
                 "traffic_source": traffic.get("source") if (args.config == 3 and grad and dtype == "f64") else None,
                 "flops_per_launch": flops_per_launch,

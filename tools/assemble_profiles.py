@@ -1,0 +1,65 @@
+"""Copies the evidence of a tools/gpu_run.sh run (gpurun_out/<run>) into profiles/ under a round tag and
+derives the PMC summary (MFMA utilisation, clock, memory-side traffic).  usage: assemble_profiles.py <run> <tag>"""
+import collections, csv, glob, json, shutil, sys
+
+run, tag = sys.argv[1], sys.argv[2]
+O, P = f"gpurun_out/{run}", "profiles"
+shutil.copy(glob.glob(f"{O}/prof/*/*_kernel_stats.csv")[0], f"{P}/{tag}_kernel_stats_bench_cfg3.csv")
+shutil.copy(glob.glob(f"{O}/prof_g1/*/*_kernel_stats.csv")[0], f"{P}/{tag}_kernel_stats_bench_cfg3_groups1.csv")
+shutil.copy(f"{O}/bench.json", f"{P}/{tag}_bench_cfg3.json")
+for line in open(f"{O}/prof_g1.log"):
+    if line.startswith('{"metric"'):
+        open(f"{P}/{tag}_bench_cfg3_groups1_under_rocprof.json", "w").write(line)
+        d = json.loads(line)
+        print("groups=1 under rocprof: dominant launch_ms", d["roofline"]["dominant_kernel"]["launch_ms"], "value", d["value"])
+for r in csv.DictReader(open(f"{P}/{tag}_kernel_stats_bench_cfg3_groups1.csv")):
+    if "true, true" in r["Name"]:
+        print(r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e6, "ms avg", float(r["MinNs"]) / 1e6, float(r["MaxNs"]) / 1e6)
+
+
+def load(t):
+    return list(csv.DictReader(open(glob.glob(f"{O}/{t}/*/*counter_collection.csv")[0])))
+
+
+out = open(f"{P}/{tag}_pmc_summary.txt", "w")
+out.write("rocprofv3 --pmc passes on `bench.py --steps 1 --warmup 1` (cfg3, default 2 sample groups + 3 single-group steps for the dominant kernel);\n"
+          "counters summed per kernel name over the run; the last block lists the W^T W launch (gemm_persist_kernel<double,true,true,128,4>) per dispatch\n")
+per = {}
+for t in ("pmc1", "pmc2", "pmc3"):
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    disp = collections.OrderedDict()
+    for r in load(t):
+        n = r["Kernel_Name"].replace("void gpc::", "").split("(")[0]
+        acc[n][r["Counter_Name"]] += float(r["Counter_Value"])
+        if "gemm_persist" in n and "true, true" in n:
+            e = disp.setdefault(int(r["Dispatch_Id"]), {})
+            e[r["Counter_Name"]] = e.get(r["Counter_Name"], 0) + float(r["Counter_Value"])
+    for n, c in sorted(acc.items()):
+        out.write(f"{t} {n[:60]:60s} " + "  ".join(f"{k}={v:.4g}" for k, v in sorted(c.items())) + "\n")
+    per[t] = disp
+out.write("\nper dispatch, W^T W launch (8-sample launches of the two groups, then the three 16-sample single-group launches):\n")
+for t in per:
+    for did, c in per[t].items():
+        out.write(f"{t} dispatch {did}: " + "  ".join(f"{k}={v:.5g}" for k, v in sorted(c.items())) + "\n")
+d1, d2, d3 = list(per["pmc1"].values())[-1], list(per["pmc2"].values())[-1], list(per["pmc3"].values())[-1]
+grbm = d3["GRBM_GUI_ACTIVE"] / 8
+busy = d1["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024
+fetch, write = d2["FETCH_SIZE"] * 1024 * 2, d3["WRITE_SIZE"] * 1024
+hit, miss = d2.get("TCC_HIT_sum", 0), d3.get("TCC_MISS_sum", 0)
+txt = (f"\nderived, 16-sample W^T W launch: MFMA busy {busy:.4g} cycles per SIMD / {grbm:.4g} GPU cycles (GRBM_GUI_ACTIVE/8) = "
+       f"{100*busy/grbm:.1f}% MFMA utilisation ({d1['SQ_VALU_MFMA_BUSY_CYCLES']/(4.016e11/2048):.1f} busy cycles per v_mfma_f64_16x16x4_f64, "
+       f"1.961e8 MFMAs tile-exact);\nmemory-side traffic = 2 x FETCH_SIZE (gfx950 correction for 16 B/lane loads) + WRITE_SIZE = "
+       f"{fetch/1e9:.2f} GB + {write/1e9:.2f} GB = {(fetch+write)/1e9:.2f} GB per launch (compulsory: 1.07 GB read of the lower half of W + "
+       f"1.07 GB write of the lower half of the inverse, 16 samples); Infinity-Cache hits are included in FETCH_SIZE; "
+       f"L2 hit rate TCC_HIT/(TCC_HIT+TCC_MISS) = {100*hit/max(1.0,hit+miss):.0f}%.\n")
+out.write(txt)
+print(txt)
+nsteps = 5
+tot_f = sum(float(r["Counter_Value"]) for r in load("pmc2") if r["Counter_Name"] == "FETCH_SIZE")
+tot_w = sum(float(r["Counter_Value"]) for r in load("pmc3") if r["Counter_Name"] == "WRITE_SIZE")
+json.dump({"dominant_kernel_traffic_bytes": fetch + write, "dominant_kernel_fetch_bytes_corrected": fetch,
+           "dominant_kernel_write_bytes": write,
+           "step_traffic_bytes": (tot_f * 2 + tot_w) * 1024 / nsteps,
+           "step_note": "all kernels of one cfg3 NLL+grad step of 16 samples (run total of the PMC passes / 5 steps): 2 x FETCH_SIZE + WRITE_SIZE",
+           "source": f"profiles/{tag}_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md)"},
+          open(f"{P}/{tag}_traffic.json", "w"), indent=1)
