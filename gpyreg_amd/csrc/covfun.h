@@ -53,13 +53,16 @@ __device__ __forceinline__ PairVal pair_eval(int kind, int degree, double r2, do
       f = 1.0 + t;
       df = 1.0;
     } else {
-      f = 1.0 + t * (1.0 + t / 3.0);
-      df = (1.0 + t) / 3.0;
+      // multiplications by 1/3 (<= 1 ulp from the reference's divisions): an fp64 division is a
+      // ~15-instruction sequence and these kernels are VALU bound, not HBM bound
+      constexpr double third = 1.0 / 3.0;
+      f = 1.0 + t * (1.0 + t * third);
+      df = (1.0 + t) * third;
     }
     o.K = sf2 * f * e;
     o.F = sf2 * (df * e);
   } else {
-    const double Mv = 1.0 + 0.5 * r2 / rqa;
+    const double Mv = 1.0 + r2 * (0.5 / rqa);  // the quotient is loop invariant
     o.K = sf2 * pow(Mv, -rqa);
     o.F = sf2 * pow(Mv, -rqa - 1.0);
     o.Ka = o.K * (0.5 * r2 / Mv - rqa * log(Mv));
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(256) void build_kernel(CovDesc cd, const double* __
         }
     }
   }
-  const double sf2 = sp[SP_SF2], rqa = sp[SP_RQA], ks = sp[SP_KSCALE];
+  const double sf2 = sp[SP_SF2], rqa = sp[SP_RQA], inv_ks = 1.0 / sp[SP_KSCALE];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256) void build_kernel(CovDesc cd, const double* __
       const int i = i0 + ty + 16 * a, j = j0 + tx + 16 * c;
       double v;
       if (i < n && j < n) {
-        v = pair_eval(cd.kind, cd.degree, r2[a][c], sf2, rqa).K / ks;  // K / (sn2_div * sn2_mult), :2416
+        v = pair_eval(cd.kind, cd.degree, r2[a][c], sf2, rqa).K * inv_ks;  // K / (sn2_div * sn2_mult), :2416
         if (i == j) v += dvec[i];
       } else {
         v = (i == j) ? 1.0 : 0.0;
