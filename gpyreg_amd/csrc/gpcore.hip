@@ -30,11 +30,15 @@ namespace {
 
 std::string g_create_err;
 
+// bumped whenever a device buffer is (re)allocated: cached launch graphs hold raw pointers
+inline unsigned long long g_alloc_epoch = 0;
+
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
   hipError_t ensure(size_t need) {
     if (need <= bytes) return hipSuccess;
+    ++g_alloc_epoch;
     if (p) (void)hipFree(p);
     p = nullptr;
     bytes = 0;
@@ -162,6 +166,21 @@ struct gpc_ctx {
   DevBuf ks, vb, kss, xss, pout; // predict / predict_full / quad
   DevBuf dbg1, dbg2, dbg3;       // debug hooks / fetch staging
   PinBuf pin;                    // pinned staging for host<->device transfers (see PinBuf)
+  // Launch graphs of the device pipeline for small problems (npad <= graph_max_npad, one sample
+  // group): a single evaluation at N = 200 is ~20 dependent launches of a few microseconds each,
+  // so the launch sequence is captured once per shape and replayed (hipGraphLaunch).
+  struct GraphEntry {
+    unsigned long long key[4] = {0, 0, 0, 0};
+    unsigned long long epoch = 0;
+    hipGraphExec_t exec = nullptr;
+    unsigned long long last_use = 0;
+    double flops = 0;  // algorithmic flops of the captured sequence (host-side bookkeeping)
+  };
+  static constexpr int NGRAPH = 16;
+  GraphEntry graphs[NGRAPH];
+  unsigned long long graph_clock = 0;
+  int graph_max_npad = 1024;     // GPC_GRAPH_MAX_NPAD (0 disables)
+  bool capturing = false;
   DevBuf tile_ctr;               // counters of the persistent GEMM launches, CTR_PER_GROUP per sample group
   static constexpr int CTR_PER_GROUP = 1024;
   // Freed posterior storage, kept for the next gpc_posterior_batch: hipMalloc/hipFree of the
@@ -407,7 +426,7 @@ struct Pipe {
                        (const double*)spb, c->dvec.as<double>() + (size_t)off * npad, N, npad, Ac, sM, npad);
     HIPCHK(c, hipGetLastError());
 
-    if (f0) HIPCHK(c, hipEventRecord(f0, st));
+    if (f0 && !c->capturing) HIPCHK(c, hipEventRecord(f0, st));
     Factor<T> F;
     F.st = st;
     F.batch = n;
@@ -428,14 +447,16 @@ struct Pipe {
     const bool full_inv = (mode != MODE_NLL);
     F.potrf_inv(0, npad, full_inv, mode == MODE_POST);
     if (mode == MODE_GRAD) {
-      HIPCHK(c, hipEventRecord(c->ev_l0[gidx], st));
+      if (!c->capturing) HIPCHK(c, hipEventRecord(c->ev_l0[gidx], st));
       F.lauum(Tc, sM);
-      HIPCHK(c, hipEventRecord(c->ev_l1[gidx], st));
-      lauum_n[gidx] = n;
+      if (!c->capturing) {
+        HIPCHK(c, hipEventRecord(c->ev_l1[gidx], st));
+        lauum_n[gidx] = n;
+      }
     }
     HIPCHK(c, F.err);
     HIPCHK(c, hipGetLastError());
-    if (f1) HIPCHK(c, hipEventRecord(f1, st));
+    if (f1 && !c->capturing) HIPCHK(c, hipEventRecord(f1, st));
     c->last_flops += F.flops;
 
     // z = L^-1 r ; quad = z.z ; alpha = W^T z / sl
@@ -470,6 +491,58 @@ struct Pipe {
                            (const double*)diagq, npad, c->ng.as<double>() + (size_t)off * noise_N);
       HIPCHK(c, hipGetLastError());
     }
+    return 0;
+  }
+
+  // device_section through a cached launch graph (one sample group, main stream)
+  int graph_section(int cnt) {
+    Batch& b = *B;
+    hipStream_t st = c->st;
+    const unsigned long long key[4] = {
+        ((unsigned long long)mode << 60) | ((unsigned long long)sizeof(T) << 52) | ((unsigned long long)b.vec_noise << 48) |
+            ((unsigned long long)cnt << 24) | (unsigned long long)b.N,
+        ((unsigned long long)b.cd.kind << 48) | ((unsigned long long)b.cd.degree << 40) | ((unsigned long long)b.D << 20) |
+            ((unsigned long long)mean_N << 10) | (unsigned long long)noise_N,
+        (unsigned long long)(uintptr_t)A, (unsigned long long)(uintptr_t)W ^ ((unsigned long long)(uintptr_t)Tm << 1)};
+    gpc_ctx::GraphEntry* hit = nullptr;
+    gpc_ctx::GraphEntry* victim = &c->graphs[0];
+    for (auto& g : c->graphs) {
+      if (g.exec && g.epoch == g_alloc_epoch && g.key[0] == key[0] && g.key[1] == key[1] && g.key[2] == key[2] &&
+          g.key[3] == key[3])
+        hit = &g;
+      if (g.last_use < victim->last_use) victim = &g;
+    }
+    if (!hit) {
+      if (victim->exec) {
+        (void)hipGraphExecDestroy(victim->exec);
+        victim->exec = nullptr;
+      }
+      hipGraph_t graph = nullptr;
+      const double flops_before = c->last_flops;
+      HIPCHK(c, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+      c->capturing = true;
+      const int rc = device_section(st, 0, cnt, nullptr, nullptr);
+      c->capturing = false;
+      victim->flops = c->last_flops - flops_before;
+      const hipError_t e = hipStreamEndCapture(st, &graph);
+      if (rc) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+      }
+      HIPCHK(c, e);
+      const hipError_t ei = hipGraphInstantiate(&victim->exec, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      HIPCHK(c, ei);
+      for (int i = 0; i < 4; ++i) victim->key[i] = key[i];
+      victim->epoch = g_alloc_epoch;
+      hit = victim;
+    } else {
+      c->last_flops += hit->flops;
+    }
+    hit->last_use = ++c->graph_clock;
+    HIPCHK(c, hipEventRecord(c->ev[1], st));
+    HIPCHK(c, hipGraphLaunch(hit->exec, st));
+    HIPCHK(c, hipEventRecord(c->ev[2], st));
     return 0;
   }
 
@@ -546,7 +619,10 @@ struct Pipe {
     hc.lap("h2d");
     int groups = c->groups;
     if (cnt < 2 * groups || npad < 1024) groups = 1;
-    if (groups == 1) {
+    if (groups == 1 && c->graph_max_npad > 0 && npad <= c->graph_max_npad) {
+      int rc = graph_section(cnt);
+      if (rc) return rc;
+    } else if (groups == 1) {
       int rc = device_section(st, 0, cnt, c->ev[1], c->ev[2]);
       if (rc) return rc;
     } else {
@@ -1291,6 +1367,7 @@ int gpc_create(int device, gpc_ctx** out) {
     delete c;
     return -1;
   }
+  if (const char* e = getenv("GPC_GRAPH_MAX_NPAD")) c->graph_max_npad = atoi(e);
   if (const char* e = getenv("GPC_GROUPS")) c->groups = std::max(1, std::min((int)gpc_ctx::MAXG, atoi(e)));
   if (const char* e = getenv("GPC_SMALL_BLOCKS")) gpc::g_small_launch_blocks = atoi(e);
   if (const char* e = getenv("GPC_GEMM_FLAGS")) gpc::g_gemm_flags = atoi(e);
@@ -1310,6 +1387,8 @@ void gpc_destroy(gpc_ctx* c) {
                     &c->dvec, &c->rvec,  &c->zvec, &c->avec, &c->scal, &c->parts, &c->gout, &c->diagq,
                     &c->dmb,  &c->dsn2b, &c->mg,  &c->ng,   &c->ks,   &c->vb,   &c->xss,  &c->pout, &c->kss,
                     &c->dbg1, &c->dbg2,  &c->dbg3, &c->tpart, &c->tile_ctr};
+  for (auto& g : c->graphs)
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
   for (DevBuf* b : bufs) b->release();
   c->pool_drain();
   c->pin.release();
