@@ -100,3 +100,32 @@ np.savez(sys.argv[1], nlz=nlz, dnlz=dnlz, mu=mu, s2=s2, C=C, a=np.stack([p.alpha
         outs.append(np.load(f))
     for k in ("nlz", "dnlz", "mu", "s2", "C", "a"):
         assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+def test_replayed_launch_graph_follows_new_inputs_and_new_data():
+    """Small problems replay a cached hipGraph of the launch sequence: the replays must see the
+    hyperparameters of each call (device buffers are refilled, pointers are not), a changed data
+    set of the same shape, a changed shape, and a jitter retry (different sample count)."""
+    model, X, y, hyp = _problem(200, 3, 4, kernel="matern", degree=3, seed=5)
+    gp = _gp(model, 3)
+    gp.update(X_new=X, y_new=y, hyp=hyp[:1], compute_posterior=False)
+    ref = [orc.core(model, hyp[s], X, y, None, 1, 1) for s in range(4)]
+    for rep in range(3):  # same shape again and again, different hyperparameters each call
+        for s in (0, 1, 2, 3, 1):
+            n, d = gp._GP__compute_nlZ(hyp[s], True, False)
+            assert abs(n - ref[s][0]) <= 1e-9 * max(1.0, abs(ref[s][0]))
+            assert np.allclose(d, ref[s][1], rtol=1e-8, atol=1e-10)
+    nb, db = gp.nll_batch(hyp, compute_grad=True)  # another sample count: another graph
+    assert np.allclose(nb, [r[0] for r in ref], rtol=1e-9)
+    # new data of the same shape through the same graph
+    model2, X2, y2, _ = _problem(200, 3, 4, kernel="matern", degree=3, seed=6)
+    gp2 = _gp(model, 3)
+    gp2.update(X_new=X2, y_new=y2, hyp=hyp[:1], compute_posterior=False)
+    n2, d2 = gp2._GP__compute_nlZ(hyp[0], True, False)
+    r2 = orc.core(model, hyp[0], X2, y2, None, 1, 1)
+    assert abs(n2 - r2[0]) <= 1e-9 * max(1.0, abs(r2[0])) and np.allclose(d2, r2[1], rtol=1e-8, atol=1e-10)
+    # and the first problem is still right afterwards (its graph, if still cached, reads X from dX)
+    gp3 = _gp(model, 3)
+    gp3.update(X_new=X, y_new=y, hyp=hyp[:1], compute_posterior=False)
+    n3, _ = gp3._GP__compute_nlZ(hyp[2], True, False)
+    assert abs(n3 - ref[2][0]) <= 1e-9 * max(1.0, abs(ref[2][0]))
