@@ -29,11 +29,19 @@
 
 namespace gpc {
 
-constexpr int BKT = 16;       // k-slab per LDS stage
-constexpr int LDQ = BKT + 1;  // stride of an m-major LDS image  [BT][17]
+// k-slab per LDS stage: 16 for fp64, 32 for fp32 -- the same 64 KB of LDS per block and the same
+// MFMA time per slab (64 x 64 cycles, 128 x 32 cycles), so the per-slab barrier and staging are
+// amortised equally in both precisions
+template <typename T>
+constexpr int BKT_v = sizeof(T) == 4 ? 32 : 16;
+template <typename T>
+constexpr int LDQ_v = BKT_v<T> + 1;  // stride of an m-major LDS image  [BT][17 | 33]
 // stride of a k-major LDS image [16][BT+16]; elements reserved per operand per stage
 constexpr int ldp_of(int BT) { return BT + 16; }
-constexpr int opsz_of(int BT) { return BKT * (BT + 16) > BT * LDQ ? BKT * (BT + 16) : BT * LDQ; }
+template <typename T>
+constexpr int opsz_of(int BT) {
+  return BKT_v<T> * (BT + 16) > BT * LDQ_v<T> ? BKT_v<T> * (BT + 16) : BT * LDQ_v<T>;
+}
 
 enum { KLO_ZERO = 0, KLO_ROW = 1, KLO_COL = 2 };  // k0 = 0 | ti*128 | tj*128
 enum { KHI_FULL = 0, KHI_ROW = 1, KHI_COL = 2 };  // k1 = K | (ti+1)*128 | (tj+1)*128
@@ -63,7 +71,7 @@ template <typename T, bool KM, int BT, int NT>
 __device__ __forceinline__ unsigned stage_toff(int ld, int t) {
   constexpr int VEC = MM<T>::VEC;
   if constexpr (!KM) {  // stored [row][k]
-    constexpr int TPR = BKT / VEC;  // threads per row
+    constexpr int TPR = BKT_v<T> / VEC;  // threads per row
     return (unsigned)(t / TPR) * (unsigned)ld + (unsigned)((t % TPR) * VEC);
   } else {  // stored [k][row]
     constexpr int VPR = BT / VEC;  // vectors per k-row
@@ -75,7 +83,7 @@ template <typename T, bool KM, int BT, int NT>
 __device__ __forceinline__ size_t stage_pstride(int ld) {
   constexpr int VEC = MM<T>::VEC;
   if constexpr (!KM)
-    return (size_t)(NT / (BKT / VEC)) * ld;
+    return (size_t)(NT / (BKT_v<T> / VEC)) * ld;
   else
     return (size_t)(NT / (BT / VEC)) * ld;
 }
@@ -89,13 +97,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
 }
 template <typename T, bool KM, int BT, int NT>
-__device__ __forceinline__ void g2r(typename MM<T>::vec_t (&r)[(BT * BKT) / (NT * MM<T>::VEC)],
+__device__ __forceinline__ void g2r(typename MM<T>::vec_t (&r)[(BT * BKT_v<T>) / (NT * MM<T>::VEC)],
                                     __amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned pstride_bytes,
                                     unsigned voff) {
   using vec_t = typename MM<T>::vec_t;
-  constexpr int NV = (BT * BKT) / (NT * MM<T>::VEC);
+  constexpr int NV = (BT * BKT_v<T>) / (NT * MM<T>::VEC);
   static_assert(sizeof(vec_t) == 16, "16-byte staging vectors");
-  static_assert(KM ? (NT % (BT / MM<T>::VEC) == 0) : (NT % (BKT / MM<T>::VEC) == 0), "pass layout");
+  static_assert(KM ? (NT % (BT / MM<T>::VEC) == 0) : (NT % (BKT_v<T> / MM<T>::VEC) == 0), "pass layout");
 #pragma unroll
   for (int p = 0; p < NV; ++p) {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff + p * pstride_bytes, 0);
@@ -105,21 +113,21 @@ __device__ __forceinline__ void g2r(typename MM<T>::vec_t (&r)[(BT * BKT) / (NT 
 
 template <typename T, bool KM, int BT, int NT>
 __device__ __forceinline__ void r2s(T* __restrict__ s,
-                                    const typename MM<T>::vec_t (&r)[(BT * BKT) / (NT * MM<T>::VEC)],
+                                    const typename MM<T>::vec_t (&r)[(BT * BKT_v<T>) / (NT * MM<T>::VEC)],
                                     int t) {
   using vec_t = typename MM<T>::vec_t;
   constexpr int VEC = MM<T>::VEC;
-  constexpr int NV = (BT * BKT) / (NT * VEC);
+  constexpr int NV = (BT * BKT_v<T>) / (NT * VEC);
   constexpr int LDP = ldp_of(BT);
   if constexpr (!KM) {
-    constexpr int TPR = BKT / VEC;
+    constexpr int TPR = BKT_v<T> / VEC;
     constexpr int RPP = NT / TPR;
 #pragma unroll
     for (int p = 0; p < NV; ++p) {
       const int row = t / TPR + p * RPP;
       const int kc = (t % TPR) * VEC;
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) s[row * LDQ + kc + e] = r[p][e];
+      for (int e = 0; e < VEC; ++e) s[row * LDQ_v<T> + kc + e] = r[p][e];
     }
   } else {
     constexpr int VPR = BT / VEC;
@@ -136,7 +144,7 @@ __device__ __forceinline__ void r2s(T* __restrict__ s,
 template <typename T, bool KM, int BT>
 __device__ __forceinline__ T frag(const T* __restrict__ s, int r0, int kk, int lane) {
   if constexpr (!KM)
-    return s[(r0 + (lane & 15)) * LDQ + kk + (lane >> 4)];
+    return s[(r0 + (lane & 15)) * LDQ_v<T> + kk + (lane >> 4)];
   else
     return s[(kk + (lane >> 4)) * ldp_of(BT) + r0 + (lane & 15)];
 }
@@ -158,8 +166,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
   using acc_t = typename MM<T>::acc_t;
   using vec_t = typename MM<T>::vec_t;
   constexpr int NT = 64 * NW;
-  constexpr int NV = (BT * BKT) / (NT * MM<T>::VEC);
-  constexpr int OPSZ = opsz_of(BT);
+  constexpr int NV = (BT * BKT_v<T>) / (NT * MM<T>::VEC);
+  constexpr int OPSZ = opsz_of<T>(BT);
   constexpr int WCOLS = NW / 2;        // waves along n
   constexpr int WTM = BT / 2;          // wave tile rows
   constexpr int WTN = BT / WCOLS;      // wave tile cols
@@ -192,7 +200,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
   int k0 = g.klo == KLO_ROW ? m128 : (g.klo == KLO_COL ? n128 : 0);
   int k1 = g.khi == KHI_ROW ? m128 + TILE : (g.khi == KHI_COL ? n128 + TILE : g.K);
   if (k1 > g.K) k1 = g.K;
-  const int nk = (k1 - k0) / BKT;
+  const int nk = (k1 - k0) / BKT_v<T>;
 
   const T* __restrict__ A = reinterpret_cast<const T*>(g.A) + (size_t)by * g.sA;
   const T* __restrict__ B = reinterpret_cast<const T*>(g.B) + (size_t)by * g.sB;
@@ -212,8 +220,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
                    tob = stage_toff<T, BKM, BT, NT>(g.ldb, t) * (unsigned)sizeof(T);
     const unsigned psa = (unsigned)(stage_pstride<T, AKM, BT, NT>(g.lda) * sizeof(T)),
                    psb = (unsigned)(stage_pstride<T, BKM, BT, NT>(g.ldb) * sizeof(T));
-    const unsigned stepa = (unsigned)((AKM ? (size_t)BKT * g.lda : (size_t)BKT) * sizeof(T)),
-                   stepb = (unsigned)((BKM ? (size_t)BKT * g.ldb : (size_t)BKT) * sizeof(T));
+    const unsigned stepa = (unsigned)((AKM ? (size_t)BKT_v<T> * g.lda : (size_t)BKT_v<T>) * sizeof(T)),
+                   stepb = (unsigned)((BKM ? (size_t)BKT_v<T> * g.ldb : (size_t)BKT_v<T>) * sizeof(T));
     const __amdgpu_buffer_rsrc_t rsa = make_rsrc(AKM ? A + (size_t)k0 * g.lda + m0 : A + (size_t)m0 * g.lda + k0);
     const __amdgpu_buffer_rsrc_t rsb = make_rsrc(BKM ? B + (size_t)k0 * g.ldb + n0 : B + (size_t)n0 * g.ldb + k0);
     unsigned ua = 0, ub = 0;  // slab offsets
@@ -221,23 +229,23 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
     g2r<T, BKM, BT, NT>(rb, rsb, ub, psb, tob);
     r2s<T, AKM, BT, NT>(smem, ra, t);
     r2s<T, BKM, BT, NT>(smem + OPSZ, rb, t);
-    // slab 1 is in flight while slab 0 is multiplied (nk is a multiple of 8)
+    // slab 1 is in flight while slab 0 is multiplied (k-ranges are 128-granular: nk is a multiple of 128 / BKT >= 4)
     ua += stepa;
     ub += stepb;
     g2r<T, AKM, BT, NT>(ra, rsa, ua, psa, toa);
     g2r<T, BKM, BT, NT>(rb, rsb, ub, psb, tob);
     __syncthreads();
 
-    // Software pipeline of one k-slab (4 k-steps of MRM x MRN MFMAs) out of LDS stage CUR.
+    // Software pipeline of one k-slab (KS k-steps of MRM x MRN MFMAs) out of LDS stage CUR.
     // Measured on MI355X (tools/mfma_ladder.hip, profiles/r01g_mfma_ladder.txt): the MFMA pipe
     // stays ~98% busy only if no two memory instructions are issued back to back, so
     //   * fragments are double buffered in registers, the LDS reads of k-step s+1 go out ahead
     //     of the MFMAs of k-step s;
-    //   * the LDS writes of the next slab (stage CUR^1) are spread between the MFMAs of k-step 2,
-    //   * the block barrier sits between k-steps 2 and 3, so the first fragments of the next
-    //     slab are read during k-step 3 and no k-step waits on LDS latency;
-    //   * the global loads of the slab after next are spread between the MFMAs of k-step 3
-    //     (in flight during k-steps 0-1 of the next slab; consumed by its k-step 2).
+    //   * the LDS writes of the next slab (stage CUR^1) are spread between the MFMAs of k-step KS-2,
+    //   * the block barrier sits between the last two k-steps, so the first fragments of the next
+    //     slab are read during the last k-step and no k-step waits on LDS latency;
+    //   * the global loads of the slab after next are spread between the MFMAs of the last k-step
+    //     (in flight during the first k-steps of the next slab; consumed by its k-step KS-2).
     // WR: a next slab exists (ra/rb hold it); LD: a slab after next exists.
     T af[2][MRM], bf[2][MRN];
     auto load_frags = [&](int set, const T* a_s, const T* b_s, int kk) {
@@ -255,22 +263,23 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
     constexpr int NMEM = 2 * NV;                    // memory instructions per slab and direction
     constexpr int PER = (MRM * MRN) / NMEM;         // MFMAs between two of them
     static_assert(PER >= 1 && PER * NMEM == MRM * MRN, "interleave pattern");
-    static_assert(BKT == 16, "the slab pipeline is written for 4 k-steps");
+    constexpr int KS = BKT_v<T> / 4;  // k-steps per slab: 4 (fp64) or 8 (fp32)
+    static_assert(KS >= 4 && KS % 2 == 0, "fragment sets alternate per k-step and wrap per slab");
     auto slab = [&](auto cur_c, auto wr_c, auto ld_c) {
       constexpr int CUR = decltype(cur_c)::value;
       constexpr bool WR = decltype(wr_c)::value, LD = decltype(ld_c)::value;
       const T* a_s = smem + CUR * 2 * OPSZ;
       const T* b_s = a_s + OPSZ;
       T* a_n = smem + (CUR ^ 1) * 2 * OPSZ;
-      load_frags(1, a_s, b_s, 4);
-      mfmas(0);
-      __builtin_amdgcn_sched_group_barrier(0x100, MRM + MRN, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, MRM * MRN, 0);
-      load_frags(0, a_s, b_s, 8);
-      mfmas(1);
-      __builtin_amdgcn_sched_group_barrier(0x100, MRM + MRN, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, MRM * MRN, 0);
-      load_frags(1, a_s, b_s, 12);
+#pragma unroll
+      for (int ks = 0; ks < KS - 2; ++ks) {
+        load_frags((ks + 1) & 1, a_s, b_s, 4 * (ks + 1));
+        mfmas(ks & 1);
+        __builtin_amdgcn_sched_group_barrier(0x100, MRM + MRN, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, MRM * MRN, 0);
+      }
+      // k-step KS-2: the LDS writes of the next slab between its MFMAs
+      load_frags(1, a_s, b_s, 4 * (KS - 1));
       mfmas(0);
       if constexpr (WR) {
         r2s<T, AKM, BT, NT>(a_n, ra, t);
@@ -283,6 +292,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
         if constexpr (WR) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
       }
       __syncthreads();
+      // k-step KS-1: the global loads of the slab after next between its MFMAs
       if constexpr (LD) {
         ua += stepa;
         ub += stepb;
@@ -306,7 +316,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
       slab(I0{}, std::true_type{}, std::true_type{});
       slab(I1{}, std::true_type{}, std::true_type{});
     }
-    // k-ranges are 128-granular (8 slabs), so exactly two slabs are left: the last one that
+    // nk is even and >= 4, so exactly two slabs are left: the last one that
     // still stages a successor, and the last one
     slab(I0{}, std::true_type{}, std::false_type{});
     slab(I1{}, std::false_type{}, std::false_type{});
@@ -330,7 +340,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
 
 template <typename T, bool AKM, bool BKM, int BT, int NW>
 __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) T smem[4 * opsz_of(BT)];
+  __shared__ __attribute__((aligned(16))) T smem[4 * opsz_of<T>(BT)];
   gemm_tile<T, AKM, BKM, BT, NW>(g, blockIdx.x, blockIdx.y, smem);
 }
 
@@ -348,7 +358,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(GemmArgs g) {
 constexpr int NQ = 8;
 template <typename T, bool AKM, bool BKM, int BT, int NW>
 __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_persist_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) T smem[4 * opsz_of(BT)];
+  __shared__ __attribute__((aligned(16))) T smem[4 * opsz_of<T>(BT)];
   __shared__ int next_tile;
   if (!(g.flags & 8)) {
     const int total = g.ntiles * g.batch;
