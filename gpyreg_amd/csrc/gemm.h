@@ -375,18 +375,30 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_persist_kernel(GemmArgs 
   unsigned xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   const int q0 = (int)(xcc & (NQ - 1));
+  // queue q: samples q, q + 8, ... when there are at least 8 samples; with fewer, sample q % batch
+  // and every nclass-th tile of it starting at tile q / batch (interleaved, so that each queue
+  // keeps the longest-first order), nclass = 8 / batch
+  const int nclass = g.batch >= NQ ? 1 : NQ / g.batch;
   for (int a = 0; a < NQ; ++a) {
     const int q = (q0 + a) & (NQ - 1);
-    const int nsq = (g.batch - q + NQ - 1) / NQ;  // samples q, q + 8, ... of this queue
-    const int total = g.ntiles * nsq;
+    int nsq, cls = 0, smp = q;
+    if (g.batch >= NQ) {
+      nsq = (g.batch - q + NQ - 1) / NQ;
+    } else {
+      if (q >= g.batch * nclass) continue;
+      nsq = 1;
+      smp = q % g.batch;
+      cls = q / g.batch;
+    }
     if (nsq <= 0) continue;
+    const int total = ((g.ntiles - cls + nclass - 1) / nclass) * nsq;
     for (;;) {
       if (threadIdx.x == 0) next_tile = atomicAdd(g.ctr + q, 1);
       __syncthreads();
       const int idx = __builtin_amdgcn_readfirstlane(next_tile);
       __syncthreads();
       if (idx >= total) break;
-      gemm_tile<T, AKM, BKM, BT, NW>(g, idx / nsq, q + NQ * (idx % nsq), smem);
+      gemm_tile<T, AKM, BKM, BT, NW>(g, cls + (idx / nsq) * nclass, smp + NQ * (idx % nsq), smem);
     }
   }
 }
