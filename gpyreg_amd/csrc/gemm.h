@@ -403,7 +403,6 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_persist_kernel(GemmArgs 
   }
 }
 
-inline int g_gemm_pad_lds = 0;  // experiment: extra dynamic LDS (bytes) on 128-tile launches
 inline int g_persist_spare = 0;     // tunable: GPC_PERSIST_SPARE (block slots a persistent launch leaves free)
 inline int g_block_slots = 512;     // two 128-tile blocks per CU (set from the device's CU count)
 template <typename T, int BT, int NW>
@@ -417,7 +416,7 @@ inline hipError_t launch_gemm_bt(hipStream_t st, GemmArgs g, bool akm, bool bkm,
   g.ntiles = ntiles;
   g.batch = batch;
   g.ctr = ctr;
-  const unsigned dyn = (BT == 128) ? (unsigned)g_gemm_pad_lds : 0u;
+  const unsigned dyn = 0u;
   const int cap = g_block_slots - g_persist_spare;
   if (ctr && BT == 128 && NW == 4 && cap > 0 && (long long)ntiles * batch > cap) {
     dim3 grid(cap), block(64 * NW);
@@ -447,7 +446,6 @@ inline hipError_t launch_gemm_bt(hipStream_t st, GemmArgs g, bool akm, bool bkm,
 // a quarter of the work each): the deep levels of the recursion are latency-, not
 // throughput-bound.  force_bt: 0 = choose, 64 / 128 = as given (tests).
 inline int g_small_launch_blocks = 1100;  // tunable: GPC_SMALL_BLOCKS
-inline int g_gemm_waves = 4;              // tunable: GPC_GEMM_WAVES (4 or 8) for 128-tiles
 template <typename T>
 inline hipError_t launch_gemm(hipStream_t st, GemmArgs g, bool akm, bool bkm, int batch, int force_bt = 0,
                              int* ctr = nullptr) {
@@ -455,7 +453,6 @@ inline hipError_t launch_gemm(hipStream_t st, GemmArgs g, bool akm, bool bkm, in
   const long long blocks128 = (long long)(g.lower_only ? tm * (tm + 1) / 2 : tm * tn) * batch;
   const bool small = force_bt ? (force_bt == 64) : (blocks128 < g_small_launch_blocks);
   if (small) return launch_gemm_bt<T, 64, 4>(st, g, akm, bkm, batch);
-  if (g_gemm_waves == 8) return launch_gemm_bt<T, 128, 8>(st, g, akm, bkm, batch);
   return launch_gemm_bt<T, 128, 4>(st, g, akm, bkm, batch, ctr);
 }
 

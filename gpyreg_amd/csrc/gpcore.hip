@@ -1373,8 +1373,6 @@ int gpc_create(int device, gpc_ctx** out) {
   if (const char* e = getenv("GPC_GEMM_FLAGS")) gpc::g_gemm_flags = atoi(e);
   if (const char* e = getenv("GPC_XCD_AFFINE")) gpc::g_gemm_flags = atoi(e) ? (gpc::g_gemm_flags | 8) : (gpc::g_gemm_flags & ~8);
   if (const char* e = getenv("GPC_LEAF")) gpc::g_leaf_version = atoi(e);
-  if (const char* e = getenv("GPC_GEMM_WAVES")) gpc::g_gemm_waves = atoi(e);
-  if (const char* e = getenv("GPC_GEMM_PADLDS")) gpc::g_gemm_pad_lds = atoi(e);
   *out = c;
   return 0;
 }
@@ -1641,8 +1639,6 @@ int gpc_set_option(gpc_ctx* c, const char* name, int value) {
     c->groups = std::max(1, std::min((int)gpc_ctx::MAXG, value));
   else if (n == "small_blocks")
     gpc::g_small_launch_blocks = value;
-  else if (n == "gemm_waves")
-    gpc::g_gemm_waves = value;
   else if (n == "leaf")
     gpc::g_leaf_version = value;
   else

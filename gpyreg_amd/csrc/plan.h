@@ -85,13 +85,10 @@ struct Factor {
         hipLaunchKernelGGL((leaf3_kernel<T>), dim3(batch), dim3(256), 0, st, blk(A, off, off), sA, npad,
                            blk(W, off, off), sW, npad, off, logdet, info,
                            std::max(0, std::min(TILE, nvalid - off)));
-      else if (g_leaf_version == 2)
+      else
         hipLaunchKernelGGL((leaf2_kernel<T>), dim3(batch), dim3(256), 0, st, blk(A, off, off), sA, npad,
                            blk(W, off, off), sW, npad, off, logdet, info,
                            std::max(0, std::min(TILE, nvalid - off)));
-      else
-        hipLaunchKernelGGL((leaf_kernel<T>), dim3(batch), dim3(256), 0, st, blk(A, off, off), sA, npad,
-                           blk(W, off, off), sW, npad, off, logdet, info);
       flops += (2.0 / 3.0) * TILE * (double)TILE * TILE * batch;
       ++launches;
       return;

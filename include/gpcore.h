@@ -132,9 +132,9 @@ int gpc_last_timing(gpc_ctx* ctx, double* ms_total, double* ms_factor);
  * (samples in that launch x N^3/3).                                                     */
 int gpc_last_lauum_timing(gpc_ctx* ctx, double* ms, double* flops);
 /* Tuning switches (also settable through the environment at gpc_create: GPC_GROUPS,
- * GPC_SMALL_BLOCKS, GPC_GEMM_WAVES, GPC_LEAF): "groups" = sample groups on separate HIP
+ * GPC_SMALL_BLOCKS, GPC_LEAF): "groups" = sample groups on separate HIP
  * streams (1..8), "small_blocks" = launch size below which 64x64 tiles are used,
- * "gemm_waves" = 4 | 8, "leaf" = 1 | 2.                                                  */
+ * "leaf" = 2 (scalar) | 3 (MFMA-blocked, default).                                                  */
 int gpc_set_option(gpc_ctx* ctx, const char* name, int value);
 /* fp64/fp32 MFMA issue-rate microbenchmark: achieved TFLOP/s of a register-resident
  * v_mfma_{f64,f32}_16x16x4 loop on all CUs (2 waves per SIMD), the shader cycles one
