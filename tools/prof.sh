@@ -1,6 +1,6 @@
 #!/bin/bash
 # bash tools/prof.sh <tag> <bench args...>  -> kernel stats of one bench invocation
-R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=$1; shift; O=$R/gpurun_out/$TAG; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=$1; shift; O=$R/gpurun_out/$TAG; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python3 $R/bench.py "$@" --no-cpu-baseline > $O/log.txt 2>&1
 python3 - <<PY
