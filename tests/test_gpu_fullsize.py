@@ -120,3 +120,21 @@ def test_cfg5_and_cfg4_sizes_size_independent_properties():
         pm, _ = gp.nll_batch(np.stack([hyp[0] + eps * v, hyp[0] - eps * v]))
         num = (pm[0] - pm[1]) / (2 * eps)
         assert abs(num - dnlz[0] @ v) < rtol * max(1.0, abs(num))
+
+
+def test_uneven_sample_queues_match_single_evaluations():
+    """13 samples at N=2048: the persistent GEMM serves 8 XCD queues of 2,2,2,2,2,1,1,1 samples (and
+    steals across them); every sample must equal its own single evaluation bit for bit (which runs
+    through the non-persistent 64-tile kernels), with and without the gradient."""
+    import bench
+
+    X, y, hyp = bench.synthetic_problem(2, 13)
+    gp = _gp(2)
+    gp.update(X_new=X, y_new=y, hyp=hyp[:1], compute_posterior=False)
+    nlz, dnlz = gp.nll_batch(hyp, compute_grad=True)
+    n0, _ = gp.nll_batch(hyp, compute_grad=False)
+    assert np.isfinite(nlz).all() and np.isfinite(dnlz).all()
+    assert np.allclose(n0, nlz, rtol=1e-13)
+    for s in (0, 4, 7, 8, 12):
+        n1, d1 = gp.nll_batch(hyp[s:s + 1], compute_grad=True)
+        assert n1[0] == nlz[s] and np.array_equal(d1[0], dnlz[s])
