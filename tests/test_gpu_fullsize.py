@@ -138,3 +138,38 @@ def test_uneven_sample_queues_match_single_evaluations():
     for s in (0, 4, 7, 8, 12):
         n1, d1 = gp.nll_batch(hyp[s:s + 1], compute_grad=True)
         assert n1[0] == nlz[s] and np.array_equal(d1[0], dnlz[s])
+
+
+@pytest.mark.parametrize("kernel,degree,noise", [("rq", 0, (1, 0, 0)), ("se_iso", 0, (1, 1, 0)), ("matern_iso", 3, (1, 2, 0)),
+                                                 ("matern", 3, (1, 0, 1)), ("matern", 1, (1, 0, 0))])
+def test_mid_size_every_kernel_family_against_the_oracle(kernel, degree, noise):
+    """N = 1408 (11 tiles: odd splits at every level of the recursion), 10 samples so that the large
+    products run as persistent launches with uneven XCD queues: NLL and gradient of the kernel
+    families and noise models the BASELINE configs do not touch, against the CPU oracle (1e-8)."""
+    from test_gpu_api import _gp as mk
+
+    N, D, S = 1408, 3, 10
+    rng = np.random.default_rng(N + degree + len(kernel))
+    X = rng.uniform(-3, 3, (N, D))
+    y = np.sin(X.sum(1, keepdims=True) / np.sqrt(D)) + 0.1 * rng.standard_normal((N, 1))
+    s2 = 0.01 * rng.uniform(0.5, 2.0, (N, 1)) if noise[1] else None
+    model = dict(kernel=kernel, degree=degree, mean="const", noise=noise)
+    cov_N = orc.cov_count(kernel, D)
+    noise_N = orc.noise_count(noise)
+    nl = D if cov_N > 2 else 1
+    base = np.concatenate([np.log(1.5 * np.sqrt(D)) * np.ones(nl), np.zeros(cov_N - nl),
+                           [np.log(0.1)] + [0.0] * (noise_N - 1), [0.0]])
+    hyp = base + 0.1 * rng.standard_normal((S, base.size))
+    gp = mk(model, D)
+    gp.update(X_new=X, y_new=y, s2_new=s2, hyp=hyp[:1], compute_posterior=False)
+    nlz, dnlz = gp.nll_batch(hyp, compute_grad=True)
+    for s in (0, 9):
+        rn, rd = orc.core(model, hyp[s], X, y, s2, 1, 1)
+        assert abs(nlz[s] - rn) <= 1e-8 * max(1.0, abs(rn)), (kernel, s)
+        if kernel == "matern" and degree == 1:  # NaN length-scale gradients on purpose
+            assert np.array_equal(np.isnan(dnlz[s]), np.isnan(rd))
+            m = ~np.isnan(rd)
+        else:
+            m = np.ones(rd.shape, bool)
+        scale = np.maximum(np.abs(rd[m]), np.abs(rd[m]).max())
+        assert (np.abs(dnlz[s][m] - rd[m]) <= 1e-8 * scale).all(), (kernel, s)
