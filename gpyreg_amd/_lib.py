@@ -32,6 +32,7 @@ SIGNATURES = {
     "gpc_device_info": (C.c_char_p, [_vp]),
     "gpc_set_data": (C.c_int, [_vp, _dp, _dp, C.c_int, C.c_int]),
     "gpc_cov_count": (C.c_int, [C.c_int, C.c_int]),
+    "gpc_max_n": (C.c_int, [C.c_int]),
     "gpc_kernel": (
         C.c_int,
         [_vp, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, _dp, C.c_int, C.c_int, _dp, _dp],
@@ -49,6 +50,7 @@ SIGNATURES = {
     "gpc_post_free": (C.c_int, [_vp]),
     "gpc_predict": (C.c_int, [_vp, _dp, C.c_int, _dp, _dp]),
     "gpc_post_append": (C.c_int, [_vp, _dp, _dp, C.c_double, _ip]),
+    "gpc_post_recompute": (C.c_int, [_vp, C.c_int, _ip, _dp, _dp, _dp, C.c_int, _dp, _ip, _ip]),
     "gpc_predict_full": (C.c_int, [_vp, _dp, C.c_int, _dp, _dp]),
     "gpc_quad": (C.c_int, [_vp, _dp, _dp, C.c_int, C.c_int, _dp, _dp]),
     "gpc_last_timing": (C.c_int, [_vp, _dp, _dp]),
@@ -273,16 +275,29 @@ class PostHandle:
         return fmu, fs2
 
     def append(self, m_star, sn2_star, y_new):
-        """Rank-one append of the point already added to the context's data; True if applied."""
+        """Rank-one append of the point already added to the context's data.  Returns the
+        per-sample outcome (bool array): False entries must be recomputed (``recompute``)."""
         m_star, sn2_star = _f64(m_star).ravel(), _f64(sn2_star).ravel()
         ok = np.zeros(self.S, dtype=np.int32)
         rc = self.ctx._lib.gpc_post_append(self._h, _ptr(m_star), _ptr(sn2_star), float(y_new),
                                            ok.ctypes.data_as(_ip))
         self.ctx._check(rc, "gpc_post_append")
-        applied = bool(ok.all())
-        if applied:
-            self.N += 1
-        return applied
+        self.N += 1
+        return ok.astype(bool)
+
+    def recompute(self, idx, hyp_cov, m, sn2, sn2_is_vector):
+        """Full recompute of the listed samples in place (the reference's ``full_updates``)."""
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        hyp_cov, m, sn2 = _f64(hyp_cov), _f64(m), _f64(sn2)
+        cnt = idx.size
+        mult = np.empty(cnt)
+        lchol = np.empty(cnt, dtype=np.int32)
+        info = np.empty(cnt, dtype=np.int32)
+        rc = self.ctx._lib.gpc_post_recompute(
+            self._h, cnt, idx.ctypes.data_as(_ip), _ptr(hyp_cov), _ptr(m), _ptr(sn2),
+            1 if sn2_is_vector else 0, _ptr(mult), lchol.ctypes.data_as(_ip), info.ctypes.data_as(_ip))
+        self.ctx._check(rc, "gpc_post_recompute")
+        return mult, lchol.astype(bool), info
 
     def predict_full(self, x_star):
         xs = _f64(x_star)

@@ -291,6 +291,31 @@ __global__ __launch_bounds__(256) void append_row_kernel(T* __restrict__ A_all, 
   }
 }
 
+// Low-noise parametrisation (Posterior.L = -(K + Sigma)^-1, full symmetric; gaussian_process.py:819-827):
+// with v = -au * cv (cv = 1 / v_star),
+//   L[i][j] += v[i] * au[j] (i, j < n);  L[i][n] = L[n][i] = -v[i];  L[n][n] = -cv;
+//   alpha[i] += ca * au[i],  alpha[n] = -ca.        coef = {cv, -, -, ca, -}
+// grid = ((n + 64) / 64, (n + 4) / 4), block = (64, 4): one thread per entry of the (n+1) x (n+1) block.
+template <typename T>
+__global__ void append_low_kernel(T* __restrict__ A, int ld, int n, const double* __restrict__ au,
+                                  const double* __restrict__ coef, double* __restrict__ alpha) {
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  const int i = blockIdx.y * 4 + threadIdx.y;
+  if (i > n || j > n) return;
+  const double cv = coef[0], ca = coef[3];
+  T* p = A + (size_t)i * ld + j;
+  if (i < n && j < n) {
+    *p = (T)((double)*p - au[i] * cv * au[j]);
+  } else if (i == n && j == n) {
+    *p = (T)(-cv);
+    alpha[n] = -ca;
+  } else {
+    const int k = i < n ? i : j;
+    *p = (T)(au[k] * cv);  // -v[k]
+  }
+  if (j == 0 && i < n) alpha[i] += ca * au[i];
+}
+
 // independent-chain VALU FMA loop (what the non-MFMA kernels are bounded by)
 template <typename T>
 __global__ __launch_bounds__(256) void valu_peak_kernel(T* out, int iters, long long* clk) {

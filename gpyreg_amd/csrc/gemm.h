@@ -211,6 +211,20 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
   for (int i = 0; i < MRM; ++i)
 #pragma unroll
     for (int j = 0; j < MRN; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+  // fp32: two-level accumulation.  The MFMA adds its products to the running sum one k-step after
+  // the other, so a K-long fp32 sum carries an error of ~sqrt(K) eps |sum| (measured: the fp32
+  // W^T W at N = 1408 was 3.7e-6 |A^-1| off and the gradient contraction, a difference of large
+  // terms, 1.5e-3 instead of 3e-5).  Every two k-slabs (64 k) the accumulators are folded into a second
+  // set and restart from zero: the first level only ever holds a 64-term partial sum, the second
+  // takes K/64 additions.
+  constexpr bool TWO_LEVEL = sizeof(T) == 4;
+  acc_t acc2[TWO_LEVEL ? MRM : 1][TWO_LEVEL ? MRN : 1];
+  if constexpr (TWO_LEVEL) {
+#pragma unroll
+    for (int i = 0; i < MRM; ++i)
+#pragma unroll
+      for (int j = 0; j < MRN; ++j) acc2[i][j] = acc_t{0, 0, 0, 0};
+  }
 
   if (nk > 0) {
     vec_t ra[NV], rb[NV];
@@ -315,6 +329,15 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
     for (; it + 3 < nk; it += 2) {
       slab(I0{}, std::true_type{}, std::true_type{});
       slab(I1{}, std::true_type{}, std::true_type{});
+      if constexpr (TWO_LEVEL) {
+#pragma unroll
+        for (int i = 0; i < MRM; ++i)
+#pragma unroll
+          for (int j = 0; j < MRN; ++j) {
+            acc2[i][j] += acc[i][j];
+            acc[i][j] = acc_t{0, 0, 0, 0};
+          }
+      }
     }
     // nk is even and >= 4, so exactly two slabs are left: the last one that
     // still stages a successor, and the last one
@@ -332,7 +355,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
         const int row = m0 + wr * WTM + i * 16 + MM<T>::row_of(lane, r);
         const int col = n0 + wc * WTN + j * 16 + (lane & 15);
         T* p = C + (size_t)row * g.ldc + col;
-        T v = alpha * acc[i][j][r];
+        T v;
+        if constexpr (TWO_LEVEL)
+          v = alpha * (acc[i][j][r] + acc2[i][j][r]);
+        else
+          v = alpha * acc[i][j][r];
         if (g.beta) v += *p;
         *p = v;
       }
@@ -418,16 +445,16 @@ inline hipError_t launch_gemm_bt(hipStream_t st, GemmArgs g, bool akm, bool bkm,
   g.ctr = ctr;
   const unsigned dyn = 0u;
   const int cap = g_block_slots - g_persist_spare;
-  if (ctr && BT == 128 && NW == 4 && cap > 0 && (long long)ntiles * batch > cap) {
+  if (ctr && BT == 128 && cap > 0 && (long long)ntiles * batch > cap) {
     dim3 grid(cap), block(64 * NW);
     if (!akm && !bkm)
-      hipLaunchKernelGGL((gemm_persist_kernel<T, false, false, 128, 4>), grid, block, dyn, st, g);
+      hipLaunchKernelGGL((gemm_persist_kernel<T, false, false, 128, NW>), grid, block, dyn, st, g);
     else if (!akm && bkm)
-      hipLaunchKernelGGL((gemm_persist_kernel<T, false, true, 128, 4>), grid, block, dyn, st, g);
+      hipLaunchKernelGGL((gemm_persist_kernel<T, false, true, 128, NW>), grid, block, dyn, st, g);
     else if (akm && bkm)
-      hipLaunchKernelGGL((gemm_persist_kernel<T, true, true, 128, 4>), grid, block, dyn, st, g);
+      hipLaunchKernelGGL((gemm_persist_kernel<T, true, true, 128, NW>), grid, block, dyn, st, g);
     else
-      hipLaunchKernelGGL((gemm_persist_kernel<T, true, false, 128, 4>), grid, block, dyn, st, g);
+      hipLaunchKernelGGL((gemm_persist_kernel<T, true, false, 128, NW>), grid, block, dyn, st, g);
     return hipGetLastError();
   }
   dim3 grid(ntiles, batch), block(64 * NW);

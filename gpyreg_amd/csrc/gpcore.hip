@@ -216,6 +216,11 @@ struct gpc_ctx {
   }
   double ms_total = 0, ms_factor = 0;
   double last_flops = 0;
+  // test hooks (gpc_set_option): first jitter multiplier of every factorization (the reference
+  // starts at 1, gaussian_process.py:2402) and samples whose rank-one append is declared unstable
+  double start_mult = 1.0;
+  unsigned append_fail_mask = 0;
+  int retry_runs = 0;  // device pipelines spent on jitter retries by the last call (one per level)
 };
 
 struct gpc_post {
@@ -311,6 +316,7 @@ struct Batch {
   std::vector<double> mul, dv, sp, dvec, r;
   std::vector<double> smin, mult, sl;
   std::vector<int> lchol, tries, info;
+  double mult0 = 1.0;  // first jitter multiplier (1 in the reference; a test hook can raise it)
 
   void init() {
     mul.assign((size_t)S * D, 1.0);
@@ -319,7 +325,7 @@ struct Batch {
     dvec.assign((size_t)S * npad, 1.0);
     r.assign((size_t)S * npad, 0.0);
     smin.assign(S, 0.0);
-    mult.assign(S, 1.0);
+    mult.assign(S, mult0);
     sl.assign(S, 1.0);
     lchol.assign(S, 0);
     tries.assign(S, 0);
@@ -632,7 +638,11 @@ struct Pipe {
         hipStream_t sg = c->gst[g];
         HIPCHK(c, hipStreamWaitEvent(sg, c->ev_up, 0));
         int rc = device_section(sg, lo, hi - lo, g == 0 ? c->ev[1] : nullptr, nullptr, g);
-        if (rc) return rc;
+        if (rc) {  // the groups already launched still read this call's buffers: let them drain
+          for (int h = 0; h <= g; ++h) (void)hipStreamSynchronize(c->gst[h]);
+          (void)hipStreamSynchronize(st);
+          return rc;
+        }
         HIPCHK(c, hipEventRecord(c->ev_done[g], sg));
         HIPCHK(c, hipStreamWaitEvent(st, c->ev_done[g], 0));
       }
@@ -678,16 +688,96 @@ struct Pipe {
     return 0;
   }
 
-  // one sample again and again with the x10 jitter escalation (gaussian_process.py:2413-2421)
-  int retry(int s, int slot) {
+  // Jitter escalation (gaussian_process.py:2413-2421): every sample of [s0, s0+cnt) whose
+  // factorization failed goes again with sn2_mult *= 10, up to 10 tries -- ALL failed samples of
+  // a level as ONE batch (a 1024-point design with many non-PD rows costs at most 9 extra device
+  // pipelines, not 9 per failed sample).  The sub-batch is computed in the scratch matrices
+  // wA/wW/wT (slot i = i-th failed sample); commit(s, i) runs after a level for every sample s
+  // that succeeded in slot i, before the next level overwrites the slots.
+  template <typename Commit>
+  int retry_failed(int s0, int cnt, T* wA, T* wW, T* wT, Commit&& commit) {
     Batch& b = *B;
-    b.tries[s] = 1;
-    while (b.info[s] != 0 && b.tries[s] < 10) {
-      b.mult[s] *= 10.0;
-      b.apply_mult(s);
-      b.tries[s] += 1;
-      int rc = run(s, 1, slot);
+    const int N = b.N, cov_N = b.cd.cov_N, Pn = P();
+    const int nsn = b.vec_noise ? N : 1;
+    std::vector<int> fail;
+    for (int s = s0; s < s0 + cnt; ++s)
+      if (b.info[s] != 0) {
+        fail.push_back(s);
+        b.tries[s] = 1;
+      }
+    while (!fail.empty() && b.tries[fail[0]] < 10) {
+      const int nf = (int)fail.size();
+      Batch sb;
+      sb.S = nf;
+      sb.N = N;
+      sb.D = b.D;
+      sb.npad = b.npad;
+      sb.cd = b.cd;
+      sb.vec_noise = b.vec_noise;
+      sb.y = b.y;
+      std::vector<double> hc((size_t)nf * cov_N), mm((size_t)nf * N), sn((size_t)nf * nsn), gdm, gds;
+      const bool gm = mode == MODE_GRAD && mean_N > 0, gn = mode == MODE_GRAD && noise_N > 0 && b.vec_noise;
+      if (gm) gdm.resize((size_t)nf * N * mean_N);
+      if (gn) gds.resize((size_t)nf * N * noise_N);
+      for (int i = 0; i < nf; ++i) {
+        const int s = fail[i];
+        std::copy_n(b.hyp_cov + (size_t)s * cov_N, cov_N, &hc[(size_t)i * cov_N]);
+        std::copy_n(b.m + (size_t)s * N, N, &mm[(size_t)i * N]);
+        std::copy_n(b.sn2 + (size_t)s * nsn, nsn, &sn[(size_t)i * nsn]);
+        if (gm) std::copy_n(dm + (size_t)s * N * mean_N, (size_t)N * mean_N, &gdm[(size_t)i * N * mean_N]);
+        if (gn) std::copy_n(dsn2 + (size_t)s * N * noise_N, (size_t)N * noise_N, &gds[(size_t)i * N * noise_N]);
+      }
+      sb.hyp_cov = hc.data();
+      sb.m = mm.data();
+      sb.sn2 = sn.data();
+      sb.init();
+      for (int i = 0; i < nf; ++i) {
+        const int s = fail[i];
+        b.mult[s] *= 10.0;
+        b.tries[s] += 1;
+        b.apply_mult(s);
+        sb.mult[i] = b.mult[s];
+        sb.apply_mult(i);
+      }
+      Pipe<T> q;
+      q.c = c;
+      q.B = &sb;
+      q.mode = mode;
+      q.A = wA;
+      q.W = wW;
+      q.Tm = wT;
+      q.sM = sM;
+      q.dm = gm ? gdm.data() : dm;  // scalar-noise dsn2 / absent dm are not read by the device
+      q.mean_N = mean_N;
+      q.dsn2 = gn ? gds.data() : dsn2;
+      q.noise_N = noise_N;
+      q.logdet.assign(nf, 0.0);
+      q.quad.assign(nf, 0.0);
+      q.G.assign((size_t)nf * Pn, 0.0);
+      q.mg.assign((size_t)nf * std::max(mean_N, 1), 0.0);
+      q.ng.assign((size_t)nf * std::max(noise_N, 1), 0.0);
+      int rc = q.run(0, nf, 0);
       if (rc) return rc;
+      ++c->retry_runs;
+      std::vector<int> still;
+      for (int i = 0; i < nf; ++i) {
+        const int s = fail[i];
+        b.info[s] = sb.info[i];
+        if (sb.info[i] != 0) {
+          still.push_back(s);
+          continue;
+        }
+        logdet[s] = q.logdet[i];
+        quad[s] = q.quad[i];
+        if (mode == MODE_GRAD) {
+          std::copy_n(&q.G[(size_t)i * Pn], Pn, &G[(size_t)s * Pn]);
+          if (mean_N > 0) std::copy_n(&q.mg[(size_t)i * mean_N], mean_N, &mg[(size_t)s * mean_N]);
+          if (noise_N > 0) std::copy_n(&q.ng[(size_t)i * noise_N], noise_N, &ng[(size_t)s * noise_N]);
+        }
+        rc = commit(s, i);
+        if (rc) return rc;
+      }
+      fail.swap(still);
     }
     return 0;
   }
@@ -709,7 +799,8 @@ int nll_impl(gpc_ctx* c, Batch& b, int want_grad, const double* dm, int mean_N, 
   const size_t per = 3ull * npad * npad * sizeof(T);
   int chunk = S;
   const bool forced = getenv("GPC_MEM_BUDGET_MB") != nullptr;
-  if (forced || (size_t)S * per > c->mA.bytes + c->mW.bytes + c->mT.bytes) {
+  const size_t one = (size_t)npad * npad * sizeof(T);
+  if (forced || (size_t)S * one > std::min(c->mA.bytes, std::min(c->mW.bytes, c->mT.bytes))) {
     // the workspace must grow: size the chunk to what is free (hipMemGetInfo is slow, so it is
     // only consulted here)
     c->pool_drain();
@@ -743,15 +834,13 @@ int nll_impl(gpc_ctx* c, Batch& b, int want_grad, const double* dm, int mean_N, 
   c->ms_total = c->ms_factor = 0;
   c->ms_lauum = c->flops_lauum = 0;
   c->last_flops = 0;
+  c->retry_runs = 0;
   for (int s0 = 0; s0 < S; s0 += chunk) {
     const int cnt = std::min(chunk, S - s0);
     int rc = p.run(s0, cnt, 0);
     if (rc) return rc;
-    for (int s = s0; s < s0 + cnt; ++s)
-      if (b.info[s] != 0) {
-        rc = p.retry(s, 0);
-        if (rc) return rc;
-      }
+    rc = p.retry_failed(s0, cnt, p.A, p.W, p.Tm, [](int, int) { return 0; });
+    if (rc) return rc;
   }
   const int cov_N = b.cd.cov_N;
   const int hyp_N = cov_N + noise_N + mean_N;
@@ -783,6 +872,9 @@ int check_batch_args(gpc_ctx* c, int kernel_id, int degree, int dtype, int S) {
   if (!valid_kernel(kernel_id, degree)) FAIL(c, "unknown covariance kernel / degree");
   if (dtype != GPC_F64 && dtype != GPC_F32) FAIL(c, "dtype must be GPC_F64 or GPC_F32");
   if (S <= 0) FAIL(c, "S must be positive");
+  if (c->N > gpc_max_n(dtype))
+    FAIL(c, "N is beyond the supported size for this dtype (an operand panel must stay below 2 GiB: "
+            "N <= 16384 in fp64, N <= 23168 in fp32)");
   return 0;
 }
 
@@ -801,6 +893,7 @@ void fill_batch(gpc_ctx* c, Batch& b, int kernel_id, int degree, int S, const do
   b.m = m;
   b.sn2 = sn2;
   b.y = c->hy.data();
+  b.mult0 = c->start_mult;
   b.init();
 }
 
@@ -835,6 +928,7 @@ int post_impl(gpc_ctx* c, Batch& b, gpc_post* po, double* sn2_mult, int* L_chol,
   p.quad.assign(S, 0.0);
   c->ms_total = c->ms_factor = 0;
   c->last_flops = 0;
+  c->retry_runs = 0;
   for (int s0 = 0; s0 < S; s0 += chunk) {
     const int cnt = std::min(chunk, S - s0);
     // matrices of sample s live at po->A + s*sM; the pipe indexes from `slot`
@@ -849,16 +943,23 @@ int post_impl(gpc_ctx* c, Batch& b, gpc_post* po, double* sn2_mult, int* L_chol,
                                hipMemcpyDeviceToDevice, c->st));
       return 0;
     };
-    for (int i = 0; i < cnt; ++i)
+    int nfail = 0;
+    for (int i = 0; i < cnt; ++i) {
       if (b.info[s0 + i] == 0 && save_alpha(s0 + i, i)) return -1;
-    for (int s = s0; s < s0 + cnt; ++s)
-      if (b.info[s] != 0) {
-        p.A = po->A.as<T>() + (size_t)s * p.sM;
-        p.W = po->W.as<T>() + (size_t)s * p.sM;
-        rc = p.retry(s, 0);
-        if (rc) return rc;
-        if (b.info[s] == 0 && save_alpha(s, 0)) return -1;
-      }
+      nfail += b.info[s0 + i] != 0;
+    }
+    if (nfail) {  // retried in scratch matrices, successes copied into the posterior's slots
+      HIPCHK(c, c->mA.ensure((size_t)nfail * msz));
+      HIPCHK(c, c->mW.ensure((size_t)nfail * msz));
+      rc = p.retry_failed(s0, cnt, c->mA.as<T>(), c->mW.as<T>(), c->mT.as<T>(), [&](int s, int i) -> int {
+        HIPCHK(c, hipMemcpyAsync(po->A.as<T>() + (size_t)s * p.sM, c->mA.as<T>() + (size_t)i * p.sM, msz,
+                                 hipMemcpyDeviceToDevice, c->st));
+        HIPCHK(c, hipMemcpyAsync(po->W.as<T>() + (size_t)s * p.sM, c->mW.as<T>() + (size_t)i * p.sM, msz,
+                                 hipMemcpyDeviceToDevice, c->st));
+        return save_alpha(s, i);
+      });
+      if (rc) return rc;
+    }
     // low-noise samples: Posterior.L = -(K + mult*Sigma)^-1  (gaussian_process.py:2441-2448)
     for (int s = s0; s < s0 + cnt; ++s)
       if (!b.lchol[s] && b.info[s] == 0) {
@@ -911,6 +1012,8 @@ int rhs_products(gpc_post* po, int mode, const double* xa, const double* xb, int
   const int S = po->S, N = po->N, D = po->D, npad = po->npad;
   const int mpad = pad_tile(M);
   hipStream_t st = c->st;
+  if ((long long)npad * mpad * (long long)sizeof(T) + 4096 >= (1ll << 31))
+    FAIL(c, "too many query points for one call at this N (N_pad * M_pad * sizeof(T) must stay below 2 GiB)");
   const long long sM = (long long)npad * npad;
   const long long sKs = (long long)npad * mpad;
   const long long sKss = (long long)mpad * mpad;
@@ -1195,7 +1298,8 @@ int debug_factor_impl(gpc_ctx* c, int n, const double* A, double* L, double* W, 
 }  // namespace
 
 namespace {
-// rank-one append, all samples L_chol with scalar noise (checked by the caller)
+// rank-one append (scalar noise; checked by the caller): high-noise samples get a new last row
+// of the factor and of its inverse (:776-817), low-noise samples a rank-one update of -inv (:819-827)
 template <typename T>
 int append_impl(gpc_post* po, const double* m_star, const double* sn2_star, double y_new, int* ok) {
   gpc_ctx* c = po->ctx;
@@ -1235,7 +1339,7 @@ int append_impl(gpc_post* po, const double* m_star, const double* sn2_star, doub
   HIPCHK(c, c->zvec.ensure(S * vb));
   HIPCHK(c, c->avec.ensure(S * vb));
   HIPCHK(c, c->tpart.ensure((size_t)S * (npad / TRC + 1) * vb));
-  HIPCHK(c, c->scal.ensure((size_t)S * 8 * 8));
+  HIPCHK(c, c->scal.ensure((size_t)S * 10 * 8));
   HIPCHK(c, hipMemcpyAsync(c->spb.p, po->sp.data(), (size_t)S * SP_STRIDE * 8, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(c->mulb.p, po->mul.data(), (size_t)S * D * 8, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(c->divb.p, po->dv.data(), (size_t)S * D * 8, hipMemcpyHostToDevice, st));
@@ -1264,37 +1368,73 @@ int append_impl(gpc_post* po, const double* m_star, const double* sn2_star, doub
   hipLaunchKernelGGL(trmv_t_sum_kernel, dim3(npad / 128, S), dim3(128), 0, st, (const double*)tpart, npad,
                      (const double*)nullptr, 0, 0, au);
   HIPCHK(c, hipGetLastError());
-  std::vector<double> ll(S), ka(S), coef((size_t)S * 5);
+  // low-noise samples (Posterior.L = -(K + Sigma)^-1, a FULL symmetric matrix; :819-827):
+  //   au = -L Ks,  Ks.au (-> predictive variance),  per sample (their W is not used)
+  double* au_low = c->dvec.as<double>();
+  double* d_kau = d_ka + S;
+  HIPCHK(c, c->dvec.ensure(S * vb));
+  au_low = c->dvec.as<double>();
+  bool any_low = false;
+  for (int s = 0; s < S; ++s) {
+    if (po->lchol[s]) continue;
+    any_low = true;
+    HIPCHK(c, hipMemsetAsync(au_low + (size_t)s * npad, 0, vb, st));
+    hipLaunchKernelGGL((gemv_sub_kernel<T>), dim3(npad / 4, 1), dim3(256), 0, st,
+                       (const T*)(po->A.as<T>() + (size_t)s * sM), 0ll, npad, (const double*)(ks + (size_t)s * npad),
+                       au_low + (size_t)s * npad, npad, 0, 0, npad);
+  }
+  if (any_low)
+    hipLaunchKernelGGL(dot_kernel, dim3(1, S), dim3(256), 0, st, (const double*)ks, (const double*)au_low, n, npad,
+                       d_kau);
+  HIPCHK(c, hipGetLastError());
+  std::vector<double> ll(S), ka(S), kau(S, 0.0), coef((size_t)S * 5);
   HIPCHK(c, hipMemcpyAsync(ll.data(), d_ll, S * 8, hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipMemcpyAsync(ka.data(), d_ka, S * 8, hipMemcpyDeviceToHost, st));
+  if (any_low) HIPCHK(c, hipMemcpyAsync(kau.data(), d_kau, S * 8, hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));
-  bool all_ok = true;
   for (int s = 0; s < S; ++s) {
     const double sf2 = po->sp[(size_t)s * SP_STRIDE + SP_SF2];
-    const double sl = po->sp[(size_t)s * SP_STRIDE + SP_SL];  // = sn2 * sn2_mult of the fitted noise
+    const double sl = po->sp[(size_t)s * SP_STRIDE + SP_SL];  // = sn2 * sn2_mult of the fitted noise (L_chol)
     const double sn2_eff = sn2_star[s] * po->mult[s];
-    // gaussian_process.py:784-788 (K = kss = sf2)
-    const double sqrt_arg = sn2_eff * sn2_eff + sf2 * sn2_eff - ll[s];
-    ok[s] = (sqrt_arg > 0.0 && std::abs(sn2_eff - sl) <= 1e-12 * sl) ? 1 : 0;
-    if (!ok[s]) {
-      all_ok = false;
-      continue;
+    const double mu_star = m_star[s] + ka[s];  // predictive mean at the new point
+    double* cf = &coef[(size_t)s * 5];
+    ok[s] = 0;
+    if (po->info[s] != 0 || ((c->append_fail_mask >> (s & 31)) & 1u)) continue;
+    if (po->lchol[s]) {
+      // gaussian_process.py:784-788 (K = kss = sf2)
+      const double sqrt_arg = sn2_eff * sn2_eff + sf2 * sn2_eff - ll[s];
+      if (!(sqrt_arg > 0.0 && std::abs(sn2_eff - sl) <= 1e-12 * sl)) continue;
+      const double dl = std::sqrt(sqrt_arg) / sn2_eff;   // new diagonal entry of the factor (:814)
+      const double v_star = sf2 - ll[s] / sl + sn2_eff;  // predictive variance incl. noise (:756)
+      cf[0] = 1.0 / sn2_eff;                             // Lo[n][:n] = l / sn2_eff  (:811)
+      cf[1] = dl;
+      cf[2] = -1.0 / (dl * sn2_eff);                     // W[n][:n] = -(l/sn2_eff)^T W / dl
+      cf[3] = (mu_star - y_new) / v_star;                // alpha update weight (:842)
+      cf[4] = 1.0 / sn2_eff;                             // alpha_update = W^T l / sn2_eff (:800-808)
+    } else {
+      // s2 = kss + Ks.(L Ks) = sf2 - Ks.au, clamped at 0 (:1762-1770), plus the noise (:1779)
+      const double v_star = std::max(sf2 - kau[s], 0.0) + sn2_eff;
+      cf[0] = 1.0 / v_star;                // v = -au / v_star (:821); new L = [[L + v au^T, -v], [-v^T, -1/v_star]]
+      cf[3] = (mu_star - y_new) / v_star;  // alpha += cf3 * au, alpha[n] = -cf3 (:840-844)
     }
-    const double dl = std::sqrt(sqrt_arg) / sn2_eff;       // new diagonal entry of the factor (:814)
-    const double v_star = sf2 - ll[s] / sl + sn2_eff;      // predictive variance incl. noise (:756)
-    const double mu_star = m_star[s] + ka[s];              // predictive mean at the new point
-    coef[(size_t)s * 5 + 0] = 1.0 / sn2_eff;               // Lo[n][:n] = l / sn2_eff  (:811)
-    coef[(size_t)s * 5 + 1] = dl;
-    coef[(size_t)s * 5 + 2] = -1.0 / (dl * sn2_eff);       // W[n][:n] = -(l/sn2_eff)^T W / dl
-    coef[(size_t)s * 5 + 3] = (mu_star - y_new) / v_star;  // alpha update weight (:842)
-    coef[(size_t)s * 5 + 4] = 1.0 / sn2_eff;               // alpha_update = W^T l / sn2_eff (:800-808)
+    ok[s] = 1;
   }
-  if (!all_ok) return 0;  // nothing was modified; the caller recomputes
-  double* d_coef = c->scal.as<double>() + 2 * S;
+  double* d_coef = c->scal.as<double>() + 3 * S;
   HIPCHK(c, hipMemcpyAsync(d_coef, coef.data(), coef.size() * 8, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL((append_row_kernel<T>), dim3((n + 256) / 256, S), dim3(256), 0, st, po->A.as<T>(),
-                     po->W.as<T>(), sM, npad, n, (const double*)lv, (const double*)au, npad,
-                     (const double*)d_coef, po->alpha.as<double>());
+  // Samples that cannot be appended keep their old rows: the caller recomputes them on the grown
+  // storage (gpc_post_recompute) -- the reference's per-posterior fallback (:789-798, :866-869).
+  for (int s = 0; s < S; ++s) {
+    if (!ok[s]) continue;
+    if (po->lchol[s])
+      hipLaunchKernelGGL((append_row_kernel<T>), dim3((n + 256) / 256, 1), dim3(256), 0, st,
+                         po->A.as<T>() + (size_t)s * sM, po->W.as<T>() + (size_t)s * sM, sM, npad, n,
+                         (const double*)(lv + (size_t)s * npad), (const double*)(au + (size_t)s * npad), npad,
+                         (const double*)(d_coef + (size_t)s * 5), po->alpha.as<double>() + (size_t)s * npad);
+    else
+      hipLaunchKernelGGL((append_low_kernel<T>), dim3((n + 64) / 64, (n + 4) / 4), dim3(64, 4), 0, st,
+                         po->A.as<T>() + (size_t)s * sM, npad, n, (const double*)(au_low + (size_t)s * npad),
+                         (const double*)(d_coef + (size_t)s * 5), po->alpha.as<double>() + (size_t)s * npad);
+  }
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(st));
   po->N = n + 1;
@@ -1410,6 +1550,16 @@ const char* gpc_last_error(const gpc_ctx* c) { return c ? c->err.c_str() : g_cre
 const char* gpc_device_info(gpc_ctx* c) { return c ? c->devinfo.c_str() : ""; }
 
 int gpc_cov_count(int kernel_id, int D) { return cov_count_of(kernel_id, D); }
+
+int gpc_max_n(int dtype) {
+  // The GEMM stages operands through raw buffer descriptors based at the tile origin with 32-bit
+  // byte offsets (gemm.h): a k-major panel spans (npad - 1) * npad elements, which must stay
+  // below 2^31 bytes.
+  const long long w = dtype == GPC_F32 ? 4 : 8;
+  long long n = TILE;
+  while ((n + TILE - 1) * (n + TILE) * w + 4096 < (1ll << 31)) n += TILE;
+  return (int)n;
+}
 
 int gpc_set_data(gpc_ctx* c, const double* X, const double* y, int N, int D) {
   if (!c) return -2;
@@ -1571,13 +1721,65 @@ int gpc_post_append(gpc_post* po, const double* m_star, const double* sn2_star, 
   if (!po) return -2;
   gpc_ctx* c = po->ctx;
   if (!m_star || !sn2_star || !ok) FAIL(c, "gpc_post_append: null argument");
-  for (int s = 0; s < po->S; ++s) {
-    ok[s] = 0;
-    if (po->info[s] != 0 || !po->lchol[s]) return 0;  // not applicable: the caller recomputes
-  }
   HIPCHK(c, hipSetDevice(c->device));
   return po->dtype == GPC_F64 ? append_impl<double>(po, m_star, sn2_star, y_new, ok)
                               : append_impl<float>(po, m_star, sn2_star, y_new, ok);
+}
+
+int gpc_post_recompute(gpc_post* po, int cnt, const int* idx, const double* hyp_cov, const double* m,
+                       const double* sn2, int sn2_is_vector, double* sn2_mult, int* L_chol, int* info) {
+  if (!po) return -2;
+  gpc_ctx* c = po->ctx;
+  if (cnt <= 0 || !idx || !hyp_cov || !m || !sn2 || !sn2_mult || !L_chol || !info)
+    FAIL(c, "gpc_post_recompute: bad arguments");
+  if (c->N != po->N || c->D != po->D) FAIL(c, "gpc_post_recompute: the context's data do not match the posterior");
+  for (int i = 0; i < cnt; ++i)
+    if (idx[i] < 0 || idx[i] >= po->S) FAIL(c, "gpc_post_recompute: sample index out of range");
+  HIPCHK(c, hipSetDevice(c->device));
+  Batch b;
+  fill_batch(c, b, po->cd.kind, po->cd.degree, cnt, hyp_cov, m, sn2, sn2_is_vector);
+  gpc_post tmp;
+  tmp.ctx = c;
+  tmp.dtype = po->dtype;
+  tmp.S = cnt;
+  tmp.N = c->N;
+  tmp.D = c->D;
+  tmp.npad = c->npad;
+  tmp.cd = b.cd;
+  if (tmp.npad != po->npad) FAIL(c, "gpc_post_recompute: padded size mismatch");
+  int rc = (po->dtype == GPC_F64) ? post_impl<double>(c, b, &tmp, sn2_mult, L_chol, info)
+                                  : post_impl<float>(c, b, &tmp, sn2_mult, L_chol, info);
+  if (rc == 0) {
+    const size_t w = po->dtype == GPC_F64 ? 8 : 4, msz = (size_t)po->npad * po->npad * w;
+    for (int i = 0; i < cnt && rc == 0; ++i) {
+      const int s = idx[i];
+      hipError_t e = hipMemcpyAsync((char*)po->A.p + (size_t)s * msz, (char*)tmp.A.p + (size_t)i * msz, msz,
+                                    hipMemcpyDeviceToDevice, c->st);
+      if (e == hipSuccess)
+        e = hipMemcpyAsync((char*)po->W.p + (size_t)s * msz, (char*)tmp.W.p + (size_t)i * msz, msz,
+                           hipMemcpyDeviceToDevice, c->st);
+      if (e == hipSuccess)
+        e = hipMemcpyAsync(po->alpha.as<double>() + (size_t)s * po->npad, tmp.alpha.as<double>() + (size_t)i * po->npad,
+                           (size_t)po->npad * 8, hipMemcpyDeviceToDevice, c->st);
+      if (e != hipSuccess) {
+        c->err = std::string("gpc_post_recompute copy: ") + hipGetErrorString(e);
+        rc = -1;
+        break;
+      }
+      std::copy_n(&tmp.sp[(size_t)i * SP_STRIDE], SP_STRIDE, &po->sp[(size_t)s * SP_STRIDE]);
+      std::copy_n(&tmp.mul[(size_t)i * po->D], po->D, &po->mul[(size_t)s * po->D]);
+      std::copy_n(&tmp.dv[(size_t)i * po->D], po->D, &po->dv[(size_t)s * po->D]);
+      po->mult[s] = tmp.mult[i];
+      po->lchol[s] = tmp.lchol[i];
+      po->info[s] = tmp.info[i];
+      po->sW[s] = tmp.sW[i];
+    }
+    (void)hipStreamSynchronize(c->st);
+  }
+  c->pool_give(tmp.A);
+  c->pool_give(tmp.W);
+  c->pool_give(tmp.alpha);
+  return rc;
 }
 
 int gpc_predict(gpc_post* po, const double* xstar, int M, double* fmu, double* fs2) {
@@ -1641,8 +1843,13 @@ int gpc_set_option(gpc_ctx* c, const char* name, int value) {
     gpc::g_small_launch_blocks = value;
   else if (n == "leaf")
     gpc::g_leaf_version = value;
+  else if (n == "start_mult_log10")  // test hook: first jitter multiplier 10^value
+    c->start_mult = std::pow(10.0, std::max(0, std::min(9, value)));
+  else if (n == "append_fail_mask")  // test hook: samples whose rank-one append is declared unstable
+    c->append_fail_mask = (unsigned)value;
   else
     FAIL(c, "gpc_set_option: unknown option");
+  ++g_alloc_epoch;  // cached launch graphs captured the old launch shapes
   return 0;
 }
 

@@ -112,9 +112,9 @@ class GP:
         self.covariance = covariance
         self.mean = mean
         self.noise = noise
-        self.s2 = None
-        self.X = None
-        self.y = None
+        self._token = None
+        self._post_handle = None
+        self._X = self._y = self._s2 = None
         self.posteriors = None
         self.no_prior = None  # set_bounds must not touch the priors before set_priors ran
         self.normalization_constants = None
@@ -123,8 +123,6 @@ class GP:
         if dtype not in _DTYPES:
             raise ValueError("dtype must be 'f64' or 'f32'")
         self.dtype = dtype
-        self._token = None
-        self._post_handle = None
         if getattr(covariance, "_gpc_kernel_id", None) is None:
             raise NotImplementedError(
                 "gpyreg_amd.GP runs the covariance on the device and supports the built-in "
@@ -135,6 +133,38 @@ class GP:
         self.set_priors()
 
     # ------------------------------------------------------------------ plumbing
+    # X, y and s2 are plain public attributes in the reference and its tests assign them directly
+    # (testing/test_gaussian_process.py:1139).  Here the device holds a copy of X and y, so assigning
+    # any of them marks that copy stale (re-uploaded on next use).  Mutating the arrays IN PLACE
+    # cannot be seen: call ``invalidate()`` afterwards.
+    @property
+    def X(self):
+        return self._X
+
+    @X.setter
+    def X(self, v):
+        self._X, self._token = v, None
+
+    @property
+    def y(self):
+        return self._y
+
+    @y.setter
+    def y(self, v):
+        self._y, self._token = v, None
+
+    @property
+    def s2(self):
+        return self._s2
+
+    @s2.setter
+    def s2(self, v):
+        self._s2 = v
+
+    def invalidate(self):
+        """Declare the device copy of X, y stale (after an in-place edit of ``gp.X`` / ``gp.y``)."""
+        self._token = None
+
     def _counts(self):
         cov_N = self.covariance.hyperparameter_count(self.D)
         mean_N = self.mean.hyperparameter_count(self.D)
@@ -432,7 +462,6 @@ class GP:
             self.y = y
         if s2 is not None:
             self.s2 = s2
-        self._token = None
         cov_N, noise_N, _ = self._counts()
 
         info = [self.covariance.get_bounds_info(self.X, self.y),
@@ -680,10 +709,11 @@ class GP:
     def update(self, X_new=None, y_new=None, s2_new=None, hyp=None, compute_posterior: bool = True):
         """Add data and/or replace hyperparameters, then rebuild every posterior
         (reference :691-884).  A single new observation (no ``s2``, no new ``hyp``, existing
-        posteriors in the high-noise parametrisation with scalar noise) takes the reference's
-        rank-one path (:750-844) on the device: the factor, its inverse and alpha get a new
-        last row in O(N^2).  Anything else -- and a numerically unstable append
-        (``sqrt_arg <= 0``, :789-798) -- is the full recompute loop (:870-884)."""
+        posteriors with scalar noise) takes the reference's rank-one path (:750-844) on the
+        device in O(N^2): high-noise posteriors get a new last row of the factor, of its inverse
+        and of alpha; low-noise posteriors the rank-one update of -inv (:819-827).  A posterior
+        whose append is numerically unstable (``sqrt_arg <= 0``, :789-798) is recomputed alone,
+        like the reference's ``full_updates``.  Anything else is the full recompute loop (:870-884)."""
         X_new, y_new, s2_new = self._convert_shapes(X_new, y_new, s2_new)
         if X_new is not None:
             X_new = X_new.copy()
@@ -719,16 +749,26 @@ class GP:
             self.y = y_new if self.y is None else np.concatenate((self.y, y_new))
         if s2_new is not None:
             self.s2 = s2_new if self.s2 is None else np.concatenate((self.s2, s2_new))
-        if X_new is not None or y_new is not None:
-            self._token = None  # device copy of X, y is stale
 
         if rank_one:
             self._ctx()  # uploads the extended X, y
-            if self._post_handle.append(*append_args):
-                for p in self.posteriors:  # cached host copies are stale; refetch lazily
-                    p._alpha = p._sW = p._L = None
-                    p._have = {"alpha": False, "sW": False, "L": False}
-                return
+            ok = self._post_handle.append(*append_args)
+            redo = np.flatnonzero(~ok)
+            if redo.size:  # unstable for these posteriors only: full update of exactly those (:789-798, :866-869)
+                cov_N, _, _ = self._counts()
+                hyp_r = np.stack([self.posteriors[i].hyp for i in redo])
+                pv = self._plugin_values(hyp_r, False)
+                mult, lchol, info = self._post_handle.recompute(redo, hyp_r[:, :cov_N], pv["m"], pv["sn2"], pv["vec"])
+                if np.any(info != 0):
+                    raise LinAlgError("Singular matrix for L Cholesky decomposition")
+                for k, i in enumerate(redo):
+                    m = mult[k]
+                    self.posteriors[i].sn2_mult = int(m) if m < 2**62 else m
+                    self.posteriors[i].L_chol = bool(lchol[k])
+            for p in self.posteriors:  # cached host copies are stale; refetch lazily
+                p._alpha = p._sW = p._L = None
+                p._have = {"alpha": False, "sW": False, "L": False}
+            return
 
         if hyp is None:
             hyp = self.get_hyperparameters(as_array=True)

@@ -45,6 +45,10 @@ int gpc_set_data(gpc_ctx* ctx, const double* X, const double* y, int N, int D);
 /* number of covariance hyperparameters (covariance_functions.py:59-73, :291-292;
  * isotropic_covariance_functions.py:14-28) */
 int gpc_cov_count(int kernel_id, int D);
+/* Largest N the dense stages accept for a dtype (16384 in fp64, 23168 in fp32): an operand
+ * panel is addressed through one buffer descriptor with 32-bit byte offsets and must stay
+ * below 2 GiB.  The batch entry points return -2 above it (no device needed to ask).       */
+int gpc_max_n(int dtype);
 
 /* ---- covariance.compute() (covariance_functions.py:135-186, :221-285, :301-367;
  *      isotropic_covariance_functions.py:104-161, :173-221) ------------------------
@@ -98,15 +102,23 @@ int gpc_post_free(gpc_post* post);
 int gpc_predict(gpc_post* post, const double* xstar, int M, double* fmu, double* fs2);
 
 /* ---- rank-one append of ONE training point to resident posteriors (GP.update fast path,
- *      gaussian_process.py:750-844, high-noise parametrisation with scalar noise) --------------
+ *      gaussian_process.py:750-844; scalar noise) ------------------------------------------------
  * Call gpc_set_data with the extended X (N+1 rows; the new point last) and y first.
  *   m_star[s]   mean function of sample s at the new point
  *   sn2_star[s] noise variance of sample s at the new point (noise.compute(hyp, x_new, y_new, 0))
- * Per sample: l = W Ks, sqrt_arg = sn2_eff^2 + kss sn2_eff - l.l (:784-788); the factor, its
- * inverse and alpha get their new last row in O(N^2).  ok[s] = 1 if appended.  If ANY sample is
- * not eligible (low-noise parametrisation, failed factorization) or has sqrt_arg <= 0, nothing is
- * modified and every ok[s] = 0: the caller recomputes (the reference's own fallback, :864-867). */
+ * High-noise samples (L_chol): l = W Ks, sqrt_arg = sn2_eff^2 + kss sn2_eff - l.l (:784-788); the
+ * factor, its inverse and alpha get their new last row in O(N^2) (:800-817).  Low-noise samples
+ * (Posterior.L = -inv): the rank-one update of -inv of :819-827.  The storage of EVERY sample grows
+ * to N+1.  ok[s] = 1 if sample s was appended; ok[s] = 0 (sqrt_arg <= 0, a failed factorization,
+ * or a noise value that is not the fitted scalar) leaves sample s stale: the caller recomputes
+ * exactly those samples with gpc_post_recompute -- the reference's per-posterior fallback
+ * (full_updates, :789-798 and :866-869).                                                        */
 int gpc_post_append(gpc_post* post, const double* m_star, const double* sn2_star, double y_new, int* ok);
+/* Recompute samples idx[0..cnt) of a resident posterior set in place from the context's current
+ * data (__core_computation(hyp, 0, 0) for those samples, :866-869).  Arrays as gpc_posterior_batch,
+ * one row per listed sample.                                                                      */
+int gpc_post_recompute(gpc_post* post, int cnt, const int* idx, const double* hyp_cov, const double* m,
+                       const double* sn2, int sn2_is_vector, double* sn2_mult, int* L_chol, int* info);
 
 /* ---- GP.predict_full (gaussian_process.py:1603-1650) -------------------------------------
  * fmu[j*S + s] = Ks^T alpha;  cov[s] (M x M, row-major) = K** - V^T V  or  K** + Ks^T (L Ks)
@@ -134,7 +146,9 @@ int gpc_last_lauum_timing(gpc_ctx* ctx, double* ms, double* flops);
 /* Tuning switches (also settable through the environment at gpc_create: GPC_GROUPS,
  * GPC_SMALL_BLOCKS, GPC_LEAF): "groups" = sample groups on separate HIP
  * streams (1..8), "small_blocks" = launch size below which 64x64 tiles are used,
- * "leaf" = 2 (scalar) | 3 (MFMA-blocked, default).                                                  */
+ * "leaf" = 2 (scalar) | 3 (MFMA-blocked, default).  Test hooks: "start_mult_log10" = k starts
+ * the jitter escalation of every factorization at 10^k instead of 1 (gaussian_process.py:2402),
+ * "append_fail_mask" = bit s declares the rank-one append of sample s unstable (:789-798).       */
 int gpc_set_option(gpc_ctx* ctx, const char* name, int value);
 /* fp64/fp32 MFMA issue-rate microbenchmark: achieved TFLOP/s of a register-resident
  * v_mfma_{f64,f32}_16x16x4 loop on all CUs (2 waves per SIMD), the shader cycles one

@@ -324,10 +324,16 @@ class OraclePosterior:
         self.L_chol = L_chol
 
 
-def core(model, hyp, X, y, s2, compute_nlZ, compute_nlZ_grad):
+def core(model, hyp, X, y, s2, compute_nlZ, compute_nlZ_grad, force_mult=None):
     """model = dict(kernel=..., degree=..., mean=..., noise=(c,u,r)).
 
     Returns nlZ | (nlZ, dnlZ) | OraclePosterior exactly like the reference.
+
+    ``force_mult`` (test-only, not in the reference): start -- and stay -- at this jitter
+    multiplier instead of escalating from 1 (:2413-2421), so that the arithmetic after a
+    retry can be compared at the level the DEVICE settled on when its first successful
+    level differs from LAPACK's (the level at which a near-singular Cholesky first
+    succeeds is rounding dependent).  Raises LinAlgError if LAPACK fails at that level.
     """
     N, d = X.shape
     kernel, degree = model["kernel"], model.get("degree", 0)
@@ -347,7 +353,8 @@ def core(model, hyp, X, y, s2, compute_nlZ, compute_nlZ_grad):
         sn2 = noise(model["noise"], h_noise, X, y, s2)
         m = np.reshape(mean(model["mean"], h_mean, X), (-1, 1))
         K = covariance(kernel, h_cov, X, degree=degree)
-    sn2_mult = 1
+    sn2_mult = 1 if force_mult is None else force_mult
+    tries = 10 if force_mult is None else 1
 
     L_chol = np.min(sn2) >= 1e-6  # :2404
     L = None
@@ -358,7 +365,7 @@ def core(model, hyp, X, y, s2, compute_nlZ, compute_nlZ_grad):
         else:
             sn2_div = np.min(sn2)
             sn2_mat = np.diag(sn2.ravel() / sn2_div)
-        for _ in range(10):
+        for _ in range(tries):
             try:
                 L = sla.cholesky(
                     K / (sn2_div * sn2_mult) + sn2_mat, check_finite=False
@@ -374,7 +381,7 @@ def core(model, hyp, X, y, s2, compute_nlZ, compute_nlZ_grad):
             sn2_mat = sn2 * np.eye(N)
         else:
             sn2_mat = np.diag(sn2.ravel())
-        for _ in range(10):
+        for _ in range(tries):
             try:
                 L = sla.cholesky(K + sn2_mult * sn2_mat, check_finite=False)
             except sla.LinAlgError:
@@ -441,10 +448,110 @@ def core(model, hyp, X, y, s2, compute_nlZ, compute_nlZ_grad):
     )
 
 
-def posteriors(model, hyps, X, y, s2):
+def posteriors(model, hyps, X, y, s2, force_mult=None):
     """GP.update full-recompute loop, gaussian_process.py:870-884."""
     hyps = np.atleast_2d(hyps)
-    return [core(model, hyps[i], X, y, s2, 0, 0) for i in range(hyps.shape[0])]
+    fm = [None] * hyps.shape[0] if force_mult is None else list(force_mult)
+    return [core(model, hyps[i], X, y, s2, 0, 0, force_mult=fm[i]) for i in range(hyps.shape[0])]
+
+
+# --------------------------------------------------------------------------
+# extended-precision restatement of the same formulas (test-only yardstick)
+# --------------------------------------------------------------------------
+
+
+def _chol_ld(A):
+    """Lower Cholesky factor in np.longdouble (x87 80-bit: eps = 1.1e-19)."""
+    n = A.shape[0]
+    L = np.zeros((n, n), dtype=np.longdouble)
+    for j in range(n):
+        d = A[j, j] - L[j, :j] @ L[j, :j]
+        if not d > 0:
+            raise sla.LinAlgError("not positive definite in extended precision")
+        L[j, j] = np.sqrt(d)
+        if j + 1 < n:
+            L[j + 1:, j] = (A[j + 1:, j] - L[j + 1:, :j] @ L[j, :j]) / L[j, j]
+    return L
+
+
+def _tri_inv_ld(L):
+    n = L.shape[0]
+    W = np.zeros((n, n), dtype=np.longdouble)
+    I = np.eye(n, dtype=np.longdouble)
+    for i in range(n):
+        W[i, :] = (I[i, :] - L[i, :i] @ W[:i, :]) / L[i, i]
+    return W
+
+
+def core_extended(model, hyp, X, y, s2, sn2_mult=1, with_scale=False):
+    """nlZ, dnlZ of gaussian_process.py:2404-2508 at a GIVEN jitter multiplier with the
+    factorization, solves and contractions carried in np.longdouble (K, dK, mean and noise
+    values are the float64 ones: they are inputs of the factorization on every
+    implementation).  Also returns cond_2(A) of the factored matrix.  Small N only (pure
+    NumPy loops).  Used to put the device's and LAPACK's errors on ill-conditioned fixtures
+    on one scale: both are expected within a modest multiple of cond * eps_64 of this.
+
+    With ``with_scale`` a fifth value is returned: per gradient component the magnitude of
+    the summands the component is a signed sum of (sum_ij |A^-1_ij dK_ij| / 2sl + sum_ij
+    |alpha_i alpha_j dK_ij| / 2 and their noise / mean analogues).  On singular fixtures the terms are ~1e10 and cancel to
+    ~10: the error of any finite-precision evaluation scales with the terms, not the result."""
+    ld = np.longdouble
+    N, d = X.shape
+    kernel, degree = model["kernel"], model.get("degree", 0)
+    cov_N = cov_count(kernel, d)
+    mean_N = mean_count(model["mean"], d)
+    noise_N = noise_count(model["noise"])
+    h_noise = hyp[cov_N: cov_N + noise_N]
+    h_mean = hyp[cov_N + noise_N: cov_N + noise_N + mean_N]
+    sn2, dsn2 = noise(model["noise"], h_noise, X, y, s2, compute_grad=True)
+    m, dm = mean(model["mean"], h_mean, X, compute_grad=True)
+    with np.errstate(all="ignore"):
+        K, dK = covariance(kernel, hyp[0:cov_N], X, compute_grad=True, degree=degree)
+    r = (y - m.reshape((-1, 1))).astype(ld)
+    L_chol = np.min(sn2) >= 1e-6
+    if L_chol:
+        sn2_div = sn2 if np.isscalar(sn2) else np.min(sn2)
+        dg = np.ones(N) if np.isscalar(sn2) else sn2.ravel() / sn2_div
+        sl = ld(sn2_div) * ld(sn2_mult)
+        A = K.astype(ld) / sl + np.diag(dg.astype(ld))
+    else:
+        dg = (sn2 * np.ones(N)) if np.isscalar(sn2) else sn2.ravel()
+        sl = ld(1)
+        A = K.astype(ld) + ld(sn2_mult) * np.diag(dg.astype(ld))
+    L = _chol_ld(A)
+    W = _tri_inv_ld(L)
+    Ainv = W.T @ W
+    alpha = (Ainv @ r) / sl
+    nlZ = (r.T @ alpha / 2)[0, 0] + np.sum(np.log(np.diag(L))) + N * np.log(2 * ld(np.pi) * sl) / 2
+    Q = Ainv / sl - alpha @ alpha.T
+    dnlZ = np.zeros(hyp.shape, dtype=ld)
+    gscale = np.zeros(hyp.shape)
+    aa = alpha @ alpha.T
+    with np.errstate(all="ignore"):
+        for i in range(cov_N):
+            dKi = dK[:, :, i].astype(ld)
+            dnlZ[i] = np.sum(Q * dKi) / 2
+            gscale[i] = float(np.nansum(np.abs(Ainv * dKi)) / sl + np.nansum(np.abs(aa * dKi))) / 2
+    if np.isscalar(sn2):
+        for i in range(noise_N):
+            dnlZ[cov_N + i] = 0.5 * sn2_mult * ld(dsn2[0, i]) * np.trace(Q)
+            gscale[cov_N + i] = float(0.5 * sn2_mult * abs(dsn2[0, i]) * (np.trace(Ainv) / sl + np.trace(aa)))
+    else:
+        for i in range(noise_N):
+            dnlZ[cov_N + i] = 0.5 * sn2_mult * np.sum(dsn2[:, i].astype(ld) * np.diag(Q))
+            gscale[cov_N + i] = float(0.5 * sn2_mult * np.sum(np.abs(dsn2[:, i]) * (np.diag(Ainv) / sl + np.diag(aa))))
+    if mean_N > 0:
+        dnlZ[cov_N + noise_N:] = (-(np.asarray(dm).astype(ld)).T @ alpha)[:, 0]
+        gscale[cov_N + noise_N:] = (np.abs(np.asarray(dm)).T @ np.abs(alpha).astype(float))[:, 0]
+    # 2-norm condition number of A from its float64 eigenvalues, clamped below by the
+    # extended-precision estimate |A|_F |A^-1|_F / N when float64 loses the small end
+    ev = np.linalg.eigvalsh(A.astype(float))
+    cond = float(ev[-1] / ev[0]) if ev[0] > 0 else np.inf
+    cond_f = float(np.sqrt(np.sum(A * A)) * np.sqrt(np.sum(Ainv * Ainv))) / N
+    cond = max(cond, cond_f) if np.isfinite(cond) else max(cond_f, 1.0)
+    if with_scale:
+        return float(nlZ), dnlZ.astype(float), cond, bool(L_chol), gscale
+    return float(nlZ), dnlZ.astype(float), cond, bool(L_chol)
 
 
 # --------------------------------------------------------------------------

@@ -13,7 +13,12 @@ Files written next to this script:
   core_cases.npz   GP.__compute_nlZ (nlZ, dnlZ), Posterior fields, GP.predict
   prior_cases.npz  GP.__compute_log_priors, normalization constants, f_min_fill designs
   full_cases.npz   GP.predict_full (with and without noise) and GP.quad
-  fit_cases.npz    GP.fit end to end under a fixed global seed (hyp samples, predictions)
+  fit_cases.npz    GP.fit end to end under a fixed global seed (hyp samples, predictions);
+                   f2 = the reference's own examples/example_1.py model and data
+  fullsize_cases.npz   nlZ and dnlZ of BASELINE cfg2 (sample 0) and cfg3 (samples 0, 1, 15)
+                   at full size (N = 2048 / 4096), a few dozen doubles
+  rank1_cases.npz  GP.update with ONE new point (the reference's rank-one path,
+                   gaussian_process.py:750-844), high- and low-noise parametrisation
 """
 
 import os
@@ -378,8 +383,111 @@ def full_cases():
     print("full cases:", len(names))
 
 
+def _bench_problem(cfg_idx, N, D, kernel, S):
+    """The synthetic workload of SURVEY.md 8(d) (same draws as bench.py / the oracle)."""
+    rng = np.random.default_rng(1000 + cfg_idx)
+    X = rng.uniform(-3, 3, (N, D))
+    y = np.sin(np.sum(X, 1, keepdims=True) / np.sqrt(D)) + 0.1 * rng.standard_normal((N, 1))
+    base = [np.log(1.5 * np.sqrt(D) * (1 + 0.1 * d / D)) for d in range(D)] + [0.0]
+    if kernel == "rq":
+        base.append(0.0)
+    base = np.asarray(base + [np.log(0.1), 0.0])
+    hyp = base + 0.1 * rng.standard_normal((S, base.size))
+    return X, y, hyp
+
+
+def fullsize_cases():
+    """nlZ, dnlZ of the reference at the BASELINE configurations' full sizes.  Inputs are
+    NOT stored: they are regenerated from the seed (bench.synthetic_problem)."""
+    import time
+
+    out = {}
+    for cfg_idx, N, D, kname, S, rows in [(2, 2048, 5, "se", 1, [0]), (3, 4096, 10, "matern5", 16, [0, 1, 15])]:
+        X, y, hyp = _bench_problem(cfg_idx, N, D, kname, S)
+        gp = gpr.GP(D=D, covariance=KERNELS[kname](), mean=MEANS["const"](), noise=make_noise((1, 0, 0)))
+        gp.X, gp.y = X, y
+        nl, dn = [], []
+        for s in rows:
+            t0 = time.time()
+            a, b = gp._GP__compute_nlZ(hyp[s], True, False)
+            nl.append(a)
+            dn.append(b)
+            print(f"cfg{cfg_idx} s={s}: nlZ={a!r} ({time.time() - t0:.1f} s)", flush=True)
+        out[f"cfg{cfg_idx}_rows"] = np.array(rows)
+        out[f"cfg{cfg_idx}_hyp"] = hyp[rows]
+        out[f"cfg{cfg_idx}_nlZ"] = np.array(nl)
+        out[f"cfg{cfg_idx}_dnlZ"] = np.stack(dn)
+        out[f"cfg{cfg_idx}_Xsum"] = np.array([X.sum(), y.sum()])  # guards the regenerated inputs
+    np.savez_compressed(os.path.join(HERE, "fullsize_cases.npz"), **out)
+
+
+def rank1_cases():
+    """GP.update(X_new=1 point, y_new) through the reference's rank-one path (:750-844):
+    three consecutive appends; posterior fields after the last one, predictions after each."""
+    out = {}
+    names = []
+    # "low": constant noise below the 1e-6 switch (L_chol False, Posterior.L = -inv) with a rough,
+    # short-lengthscale kernel so that K + sn2 I stays well conditioned and the fixture is not
+    # rounding dependent
+    cases = [("se", "const", (1, 0, 0), 33, 2, "high"), ("matern5", "const", (1, 0, 0), 126, 3, "high"),
+             ("se", "negquad", (1, 0, 0), 128, 2, "high"), ("matern1", "const", (1, 0, 0), 33, 2, "low"),
+             ("matern3", "zero", (1, 0, 0), 127, 2, "low"), ("rq", "const", (1, 0, 0), 40, 2, "high"),
+             ("matern3", "const", (1, 0, 0), 128, 3, "low")]
+    for idx, (kname, mname, npar, N, D, flav) in enumerate(cases):
+        rng = np.random.default_rng(17000 + idx)
+        cov, mean, noise = KERNELS[kname](), MEANS[mname](), make_noise(npar)
+        gp = gpr.GP(D=D, covariance=cov, mean=mean, noise=noise)
+        cov_N, mean_N, noise_N = cov.hyperparameter_count(D), mean.hyperparameter_count(D), noise.hyperparameter_count()
+        X = rng.uniform(-3, 3, (N, D))
+        y = np.sin(np.sum(X, 1, keepdims=True) / np.sqrt(D)) + 0.1 * rng.standard_normal((N, 1))
+        S = 3
+        hyp = np.zeros((S, cov_N + noise_N + mean_N))
+        for s in range(S):
+            h_cov = 0.2 * rng.standard_normal(cov_N)
+            h_cov[:D] += np.log(1.2 * np.sqrt(D)) if flav == "high" else np.log(0.4)
+            h_noise = [(np.log(0.1) if flav == "high" else np.log(3e-4)) + 0.2 * rng.standard_normal()]
+            h_mean = {"zero": [], "const": [0.2 * rng.standard_normal()]}.get(
+                mname, [0.2 * rng.standard_normal()] + list(0.5 * rng.standard_normal(D))
+                + list(np.log(4.0) + 0.2 * rng.standard_normal(D)))
+            hyp[s] = np.concatenate([h_cov, h_noise, h_mean])
+        gp.update(X_new=X, y_new=y, hyp=hyp)
+        assert all(p.sn2_mult == 1 for p in gp.posteriors)
+        assert all(bool(p.L_chol) == (flav == "high") for p in gp.posteriors)
+        tag = f"r{idx:03d}"
+        names.append(f"{tag}|{kname}|{mname}|{npar[0]}{npar[1]}{npar[2]}|{N}|{D}|{flav}")
+        out[tag + "_X"], out[tag + "_y"], out[tag + "_hyp"] = X, y, hyp
+        xs = rng.uniform(-3.5, 3.5, (7, D))
+        out[tag + "_xs"] = xs
+        Xn = rng.uniform(-3, 3, (3, D))
+        yn = np.sin(np.sum(Xn, 1, keepdims=True) / np.sqrt(D)) + 0.1 * rng.standard_normal((3, 1))
+        out[tag + "_Xn"], out[tag + "_yn"] = Xn, yn
+        for k in range(3):
+            import warnings
+            with warnings.catch_warnings(record=True) as wlist:
+                warnings.simplefilter("always")
+                gp.update(X_new=Xn[k:k + 1], y_new=yn[k:k + 1])
+            assert not wlist, "an unstable rank-one update would make the fixture rounding dependent"
+            mu, s2 = gp.predict(xs, separate_samples=True)
+            out[tag + f"_mu{k}"], out[tag + f"_s2{k}"] = mu, s2
+        out[tag + "_alpha"] = np.stack([p.alpha[:, 0] for p in gp.posteriors])
+        out[tag + "_sW"] = np.stack([p.sW[:, 0] for p in gp.posteriors])
+        out[tag + "_L_chol"] = np.array([bool(p.L_chol) for p in gp.posteriors])
+        out[tag + "_Ldiag"] = np.stack([np.diag(p.L) for p in gp.posteriors])
+        out[tag + "_Llast_col"] = np.stack([np.asarray(p.L)[:, -1] for p in gp.posteriors])
+        out[tag + "_Llast_row"] = np.stack([np.asarray(p.L)[-1, :] for p in gp.posteriors])
+        out[tag + "_Lfro"] = np.array([np.linalg.norm(p.L) for p in gp.posteriors])
+        conds = [np.linalg.cond(np.asarray(p.L)) for p in gp.posteriors]
+        print(names[-1], "L_chol", out[tag + "_L_chol"], "alpha[-1]", out[tag + "_alpha"][:, -1], "cond(L) %.1e" % max(conds))
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "rank1_cases.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["cov", "core", "prior", "fit", "full"]
+    which = sys.argv[1:] or ["cov", "core", "prior", "fit", "full", "fullsize", "rank1"]
+    if "fullsize" in which:
+        fullsize_cases()
+    if "rank1" in which:
+        rank1_cases()
     if "cov" in which:
         cov_cases()
     if "core" in which:

@@ -40,6 +40,40 @@ def test_cov_count_entry_point_without_gpu():
     assert lib.gpc_cov_count(99, 5) == -1
 
 
+def test_size_envelope_entry_point_without_gpu():
+    """gpc_max_n: an operand panel of the GEMM is addressed through one buffer descriptor with 32-bit
+    byte offsets, so (npad - 1) * npad * sizeof(T) must stay below 2^31; larger N is rejected by the
+    batch entry points (-2) instead of silently reading zeros."""
+    from gpyreg_amd import _lib
+
+    lib = _lib.load()
+    for dtype, w in ((_lib.F64, 8), (_lib.F32, 4)):
+        n = lib.gpc_max_n(dtype)
+        assert n % 128 == 0
+        assert (n - 1) * n * w + 4096 < 2**31 <= (n + 127) * (n + 128) * w + 4096
+    assert lib.gpc_max_n(_lib.F64) == 16384 and lib.gpc_max_n(_lib.F32) == 23168
+
+
+def test_assigning_data_attributes_marks_the_device_copy_stale():
+    """gp.X = ..., gp.y = ... (the reference's tests assign them directly) must invalidate the
+    resident copy; invalidate() covers in-place edits."""
+    import gpyreg_amd as gpr
+
+    gp = gpr.GP(2, gpr.covariance_functions.SquaredExponential(), gpr.mean_functions.ConstantMean(),
+                gpr.noise_functions.GaussianNoise(constant_add=True))
+    gp._token = object()
+    gp.y = np.zeros((3, 1))
+    assert gp._token is None and gp.y.shape == (3, 1)
+    gp._token = object()
+    gp.X = np.zeros((3, 2))
+    assert gp._token is None
+    gp._token = object()
+    gp.s2 = np.ones((3, 1))
+    assert gp._token is not None  # s2 is not resident: it reaches the device through the noise values
+    gp.invalidate()
+    assert gp._token is None
+
+
 @pytest.mark.skipif(_has_gpu(), reason="only meaningful on a box without a GPU")
 def test_product_path_fails_loudly_without_gpu():
     import gpyreg_amd as gpr

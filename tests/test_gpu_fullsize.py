@@ -1,6 +1,6 @@
-"""Full-size GPU checks at BASELINE.json's configurations through size-independent
-properties, plus the two full-size reference values SURVEY.md 8(d) recorded (they were
-produced by the reference itself at survey time)."""
+"""Full-size GPU checks at BASELINE.json's configurations: nlZ and gradient against values
+produced by the reference itself at full size (tests/golden/fullsize_cases.npz), in fp64
+(1e-8) and fp32 (1e-3), plus size-independent properties."""
 
 import numpy as np
 import pytest
@@ -52,6 +52,53 @@ def test_cfg3_reference_value_gradient_and_batch_consistency():
     pm, _ = gp.nll_batch(np.stack([hyp[0] + eps * v, hyp[0] - eps * v]))
     num = (pm[0] - pm[1]) / (2 * eps)
     assert abs(num - dnlz[0] @ v) < 1e-6 * max(1.0, abs(num))
+
+
+def test_headline_sizes_match_reference_goldens_1e8():
+    """north_star bar at the sizes it is quoted on: nlZ AND the full gradient of cfg2 (N=2048,
+    sample 0) and cfg3 (N=4096, samples 0, 1, 15 of the 16) against values produced by running
+    the reference itself at full size (tests/golden/fullsize_cases.npz, make_golden.py fullsize),
+    1e-8 relative; the inputs are regenerated from the seed and checked against the fixture."""
+    import os
+
+    import bench
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fullsize_cases.npz"), allow_pickle=False)
+    for cfg, S in [(2, 1), (3, 16)]:
+        X, y, hyp = bench.synthetic_problem(cfg, S)
+        rows = g[f"cfg{cfg}_rows"]
+        assert np.array_equal(hyp[rows], g[f"cfg{cfg}_hyp"])
+        assert np.allclose([X.sum(), y.sum()], g[f"cfg{cfg}_Xsum"], rtol=1e-13)
+        gp = _gp(cfg)
+        gp.update(X_new=X, y_new=y, hyp=hyp[:1], compute_posterior=False)
+        nlz, dnlz = gp.nll_batch(hyp, compute_grad=True)
+        for k, s in enumerate(rows):
+            rn, rd = g[f"cfg{cfg}_nlZ"][k], g[f"cfg{cfg}_dnlZ"][k]
+            e_n = abs(nlz[s] - rn) / max(1.0, abs(rn))
+            e_d = (np.abs(dnlz[s] - rd) / np.maximum(np.abs(rd), np.abs(rd).max())).max()
+            print(f"cfg{cfg} sample {s}: nlZ rel err {e_n:.2e}, gradient rel err {e_d:.2e}")
+            assert e_n < 1e-8 and e_d < 1e-8, (cfg, s, e_n, e_d)
+
+
+def test_fp32_full_size_against_reference_goldens():
+    """fp32 mode at N=2048 / N=4096 against the same reference values: 1e-3 relative."""
+    import os
+
+    import bench
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fullsize_cases.npz"), allow_pickle=False)
+    for cfg, S in [(2, 1), (3, 16)]:
+        X, y, hyp = bench.synthetic_problem(cfg, S)
+        rows = g[f"cfg{cfg}_rows"]
+        gp = bench.make_gp(cfg, "f32")
+        gp.update(X_new=X, y_new=y, hyp=hyp[:1], compute_posterior=False)
+        nlz, dnlz = gp.nll_batch(hyp[rows], compute_grad=True)
+        for k in range(len(rows)):
+            rn, rd = g[f"cfg{cfg}_nlZ"][k], g[f"cfg{cfg}_dnlZ"][k]
+            e_n = abs(nlz[k] - rn) / max(1.0, abs(rn))
+            e_d = (np.abs(dnlz[k] - rd) / np.maximum(np.abs(rd), np.abs(rd).max())).max()
+            print(f"fp32 cfg{cfg} sample {rows[k]}: nlZ rel err {e_n:.2e}, gradient rel err {e_d:.2e}")
+            assert e_n < 1e-3 and e_d < 1e-3, (cfg, k, e_n, e_d)
 
 
 def test_predict_interpolates_at_full_size():
@@ -163,13 +210,19 @@ def test_mid_size_every_kernel_family_against_the_oracle(kernel, degree, noise):
     gp = mk(model, D)
     gp.update(X_new=X, y_new=y, s2_new=s2, hyp=hyp[:1], compute_posterior=False)
     nlz, dnlz = gp.nll_batch(hyp, compute_grad=True)
+    gp32 = mk(model, D, dtype="f32")  # the fp32 path against the SAME oracle values, 1e-3
+    gp32.update(X_new=X, y_new=y, s2_new=s2, hyp=hyp[:1], compute_posterior=False)
+    nlz32, dnlz32 = gp32.nll_batch(hyp, compute_grad=True)
     for s in (0, 9):
         rn, rd = orc.core(model, hyp[s], X, y, s2, 1, 1)
         assert abs(nlz[s] - rn) <= 1e-8 * max(1.0, abs(rn)), (kernel, s)
+        assert abs(nlz32[s] - rn) <= 1e-3 * max(1.0, abs(rn)), (kernel, s, "f32")
         if kernel == "matern" and degree == 1:  # NaN length-scale gradients on purpose
             assert np.array_equal(np.isnan(dnlz[s]), np.isnan(rd))
+            assert np.array_equal(np.isnan(dnlz32[s]), np.isnan(rd))
             m = ~np.isnan(rd)
         else:
             m = np.ones(rd.shape, bool)
         scale = np.maximum(np.abs(rd[m]), np.abs(rd[m]).max())
         assert (np.abs(dnlz[s][m] - rd[m]) <= 1e-8 * scale).all(), (kernel, s)
+        assert (np.abs(dnlz32[s][m] - rd[m]) <= 1e-3 * scale).all(), (kernel, s, "f32")
