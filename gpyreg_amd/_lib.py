@@ -13,7 +13,8 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgpcore.so")
+# GPYREG_AMD_LIB: another build of the same library (A/B measurements of kernel variants)
+LIB_PATH = os.environ.get("GPYREG_AMD_LIB") or os.path.join(_HERE, "lib", "libgpcore.so")
 
 K_SE, K_MATERN, K_RQ, K_SE_ISO, K_MATERN_ISO = range(5)
 F64, F32 = 0, 1

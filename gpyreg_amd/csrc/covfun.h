@@ -89,17 +89,148 @@ constexpr int DCH = 32;  // input dimensions staged in LDS per pass
 // stage rows [r0, r0+64) of Xs, dims [h0, h0+dc) into sh[64][DCH+1]
 __device__ __forceinline__ void stage_x(double (*sh)[DCH + 1], const double* __restrict__ Xs, int D,
                                         int r0, int h0, int dc, int t) {
-  for (int e = t; e < CT * dc; e += 256) {
-    const int r = e / dc, h = e % dc;
-    sh[r][h] = Xs[(size_t)(r0 + r) * D + h0 + h];
+  const int r = t >> 2;  // 4 threads per row, no integer division by the runtime chunk width
+  for (int h = t & 3; h < dc; h += 4) sh[r][h] = Xs[(size_t)(r0 + r) * D + h0 + h];
+}
+
+// ---------------------------------------------------------------------------------
+// Pair evaluation specialised at compile time on (kernel family, Matern degree): the N^2 passes
+// below are fp64-VALU bound, so the family switch is taken once per launch (launch_build /
+// launch_trace), the square root is the hardware rsq estimate + one Newton step + one
+// correction (<= 1 ulp, 9 instructions instead of the ~20 of a correctly rounded division-based
+// sqrt) and the rational quadratic needs one log, one exp and one reciprocal instead of two pows
+// and a log:  M^-a = exp(-a log M),  M^(-a-1) = M^-a / M.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ double sqrt_fast(double x) {
+  double r = __builtin_amdgcn_rsq(x);      // ~5e-8 relative; +inf at 0
+  r = r * fma(-0.5 * x, r * r, 1.5);        // one Newton step: ~4e-15
+  double t = x * r;
+  const double e = fma(-t, t, x);           // residual x - t^2
+  t = fma(e, 0.5 * r, t);                   // t + e / (2 sqrt(x)): <= 1 ulp
+  return x > 0.0 ? t : 0.0;
+}
+__device__ __forceinline__ double rcp_fast(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+
+// exp(x) for the arguments of the covariance functions (x <= 0 up to rounding; any finite x works,
+// overflow is not handled).  Cody-Waite reduction x = n ln2 + r, |r| <= ln2 / 2, Taylor polynomial of
+// degree 13 (truncation 4e-18), scaling by ldexp (exact; gradual underflow to 0 for x < -745).
+// The library exp costs ~46 instructions per call in these kernels: its 16 unrolled copies re-materialise
+// the fp64 polynomial coefficients with v_mov pairs each time (358 v_mov_b32 in the old trace kernel);
+// here the coefficients are read once from constant memory into scalar registers and every Horner
+// step is one v_fma_f64 with an SGPR-pair operand: 19 instructions, < 1 ulp from the library's result.
+__constant__ double GPC_EXPC[14] = {1.0,
+                                    1.0,
+                                    1.0 / 2,
+                                    1.0 / 6,
+                                    1.0 / 24,
+                                    1.0 / 120,
+                                    1.0 / 720,
+                                    1.0 / 5040,
+                                    1.0 / 40320,
+                                    1.0 / 362880,
+                                    1.0 / 3628800,
+                                    1.0 / 39916800,
+                                    1.0 / 479001600,
+                                    1.0 / 6227020800.0};
+struct ExpC {
+  double c[14];
+  __device__ __forceinline__ void load() {
+#pragma unroll
+    for (int i = 0; i < 14; ++i) c[i] = GPC_EXPC[i];
   }
+  __device__ __forceinline__ double operator()(double x) const {
+    const double n = __builtin_rint(x * 1.4426950408889634074);
+    double r = fma(-n, 6.93147180369123816490e-01, x);  // ln2 high part (trailing zeros: n * hi exact)
+    r = fma(-n, 1.90821492927058770002e-10, r);         // ln2 low part
+    double p = c[13];
+#pragma unroll
+    for (int i = 12; i >= 0; --i) p = fma(p, r, c[i]);
+    return __builtin_ldexp(p, (int)n);
+  }
+};
+
+template <int KIND, int DEG>
+__device__ __forceinline__ PairVal pair_eval_t(double r2, double sf2, double rqa, const ExpC& ex) {
+  PairVal o;
+  o.Ka = 0.0;
+  if constexpr (KIND == K_SE || KIND == K_SE_ISO) {
+    o.K = sf2 * ex(-0.5 * r2);
+    o.F = o.K;
+  } else if constexpr (KIND == K_MATERN || KIND == K_MATERN_ISO) {
+    const double t = sqrt_fast(r2);
+    const double e = sf2 * ex(-t);
+    if constexpr (DEG == 1) {
+      o.K = e;
+      o.F = e / t;  // 1/t: +inf on the diagonal, by the reference's definition (:276-279)
+    } else if constexpr (DEG == 3) {
+      o.K = fma(t, e, e);
+      o.F = e;
+    } else {
+      constexpr double third = 1.0 / 3.0;
+      o.K = e * fma(t, fma(t, third, 1.0), 1.0);
+      o.F = e * (fma(t, third, third));
+    }
+  } else {
+    const double Mv = fma(r2, 0.5 / rqa, 1.0);
+    const double lM = log(Mv);
+    const double rM = rcp_fast(Mv);
+    o.K = sf2 * ex(-rqa * lM);
+    o.F = o.K * rM;
+    o.Ka = o.K * fma(0.5 * r2, rM, -rqa * lM);
+  }
+  return o;
+}
+
+// squared distances of the 4 x 4 pairs of one thread (rows ty + 16a of tile i, rows tx + 16c of tile j),
+// dimensions summed in ascending order; leaves the LAST staged chunk of dimensions in xi / xj
+__device__ __forceinline__ void tile_r2(double (&r2)[4][4], double (*xi)[DCH + 1], double (*xj)[DCH + 1],
+                                        const double* __restrict__ Xs, int D, int i0, int j0, int t, int tx,
+                                        int ty) {
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) r2[a][c] = 0.0;
+  for (int h0 = 0; h0 < D; h0 += DCH) {
+    const int dc = min(DCH, D - h0);
+    __syncthreads();
+    stage_x(xi, Xs, D, i0, h0, dc, t);
+    stage_x(xj, Xs, D, j0, h0, dc, t);
+    __syncthreads();
+    for (int h = 0; h < dc; ++h) {
+      double vi[4], vj[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) vi[a] = xi[ty + 16 * a][h];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) vj[c] = xj[tx + 16 * c][h];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const double d = vi[a] - vj[c];
+          r2[a][c] = fma(d, d, r2[a][c]);
+        }
+    }
+  }
+}
+
+__device__ __forceinline__ void lower_tile(int bx, int& ti, int& tj) {
+  int i = (int)((sqrtf(8.f * (float)bx + 1.f) - 1.f) * 0.5f);
+  while (i * (i + 1) / 2 > bx) --i;
+  while ((i + 1) * (i + 2) / 2 <= bx) ++i;
+  ti = i;
+  tj = bx - i * (i + 1) / 2;
 }
 
 // ---------------------------------------------------------------------------------
 // A[b] (lower 64x64 tiles) = K(Xs, Xs) / sp[SP_KSCALE] + diag(dvec), identity in the padding.
 // grid = (lower tiles of npad/64, batch)
 // ---------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int KIND, int DEG>
 __global__ __launch_bounds__(256) void build_kernel(CovDesc cd, const double* __restrict__ Xs_all,
                                                     const double* __restrict__ sp_all,
                                                     const double* __restrict__ dvec_all, int n,
@@ -109,13 +240,7 @@ __global__ __launch_bounds__(256) void build_kernel(CovDesc cd, const double* __
   __shared__ double xj[CT][DCH + 1];
   const int t = threadIdx.x, tx = t & 15, ty = t >> 4, b = blockIdx.y;
   int ti, tj;
-  {
-    int i = (int)((sqrtf(8.f * (float)blockIdx.x + 1.f) - 1.f) * 0.5f);
-    while (i * (i + 1) / 2 > (int)blockIdx.x) --i;
-    while ((i + 1) * (i + 2) / 2 <= (int)blockIdx.x) ++i;
-    ti = i;
-    tj = blockIdx.x - i * (i + 1) / 2;
-  }
+  lower_tile(blockIdx.x, ti, tj);
   const int i0 = ti * CT, j0 = tj * CT;
   const double* Xs = Xs_all + (size_t)b * npad * cd.D;
   const double* sp = sp_all + (size_t)b * SP_STRIDE;
@@ -123,33 +248,11 @@ __global__ __launch_bounds__(256) void build_kernel(CovDesc cd, const double* __
   T* A = A_all + (size_t)b * sA;
 
   double r2[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) r2[a][c] = 0.0;
-
-  for (int h0 = 0; h0 < cd.D; h0 += DCH) {
-    const int dc = min(DCH, cd.D - h0);
-    __syncthreads();
-    stage_x(xi, Xs, cd.D, i0, h0, dc, t);
-    stage_x(xj, Xs, cd.D, j0, h0, dc, t);
-    __syncthreads();
-    for (int h = 0; h < dc; ++h) {
-      double vi[4], vj[4];
-#pragma unroll
-      for (int a = 0; a < 4; ++a) vi[a] = xi[ty + 16 * a][h];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) vj[c] = xj[tx + 16 * c][h];
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const double d = vi[a] - vj[c];
-          r2[a][c] += d * d;
-        }
-    }
-  }
+  tile_r2(r2, xi, xj, Xs, cd.D, i0, j0, t, tx, ty);
   const double sf2 = sp[SP_SF2], rqa = sp[SP_RQA], inv_ks = 1.0 / sp[SP_KSCALE];
+  const double sfs = sf2 * inv_ks;  // K / (sn2_div * sn2_mult), :2416
+  ExpC ex;
+  ex.load();
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -157,13 +260,27 @@ __global__ __launch_bounds__(256) void build_kernel(CovDesc cd, const double* __
       const int i = i0 + ty + 16 * a, j = j0 + tx + 16 * c;
       double v;
       if (i < n && j < n) {
-        v = pair_eval(cd.kind, cd.degree, r2[a][c], sf2, rqa).K * inv_ks;  // K / (sn2_div * sn2_mult), :2416
+        v = pair_eval_t<KIND, DEG>(r2[a][c], sfs, rqa, ex).K;
         if (i == j) v += dvec[i];
       } else {
         v = (i == j) ? 1.0 : 0.0;
       }
       A[(size_t)i * lda + j] = (T)v;
     }
+}
+
+// Sum four per-lane values over the 64 lanes of a wave with 7 exchanges instead of 24: two
+// halving steps leave each lane one value (lane bits 5, 4 select which), four more finish it.
+// On return lane l holds the wave total of v[(l >> 4) & 3].  Fixed order: deterministic.
+__device__ __forceinline__ double wave_sum4(double v0, double v1, double v2, double v3, int lane) {
+  const bool b5 = lane & 32, b4 = lane & 16;
+  double k0 = b5 ? v2 : v0, k1 = b5 ? v3 : v1;
+  k0 += __shfl_xor(b5 ? v0 : v2, 32, 64);
+  k1 += __shfl_xor(b5 ? v1 : v3, 32, 64);
+  double u = (b4 ? k1 : k0) + __shfl_xor(b4 ? k0 : k1, 16, 64);
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) u += __shfl_xor(u, o, 64);
+  return u;
 }
 
 // ---------------------------------------------------------------------------------
@@ -173,8 +290,11 @@ __global__ __launch_bounds__(256) void build_kernel(CovDesc cd, const double* __
 //   diagQ[b][i] = Q_ii
 // grid = (lower tiles of npad/64, batch).  dK is recomputed from the scaled inputs.
 // ---------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void trace_kernel(CovDesc cd, const double* __restrict__ Xs_all,
+#ifndef GPC_TRACE_WPS
+#define GPC_TRACE_WPS 1
+#endif
+template <typename T, int KIND, int DEG>
+__global__ __launch_bounds__(256, GPC_TRACE_WPS) void trace_kernel(CovDesc cd, const double* __restrict__ Xs_all,
                                                     const double* __restrict__ sp_all,
                                                     const double* __restrict__ alpha_all, int n,
                                                     int npad, const T* __restrict__ Kinv_all,
@@ -183,54 +303,42 @@ __global__ __launch_bounds__(256) void trace_kernel(CovDesc cd, const double* __
                                                     double* __restrict__ diagQ_all) {
   __shared__ double xi[CT][DCH + 1];
   __shared__ double xj[CT][DCH + 1];
-  extern __shared__ double wpart[];  // [4][P]
+  extern __shared__ double wpart[];  // [4][P4], P4 = P rounded up to a multiple of 4 (+4)
   const int t = threadIdx.x, tx = t & 15, ty = t >> 4, b = blockIdx.y;
   const int lane = t & 63, w = t >> 6;
   const int P = cd.cov_N + 1;
+  const int P4 = ((P + 3) & ~3) + 4;
+  constexpr bool ISO = (KIND == K_SE_ISO || KIND == K_MATERN_ISO);
   int ti, tj;
-  {
-    int i = (int)((sqrtf(8.f * (float)blockIdx.x + 1.f) - 1.f) * 0.5f);
-    while (i * (i + 1) / 2 > (int)blockIdx.x) --i;
-    while ((i + 1) * (i + 2) / 2 <= (int)blockIdx.x) ++i;
-    ti = i;
-    tj = blockIdx.x - i * (i + 1) / 2;
-  }
+  lower_tile(blockIdx.x, ti, tj);
   const int i0 = ti * CT, j0 = tj * CT;
   const double* Xs = Xs_all + (size_t)b * npad * cd.D;
   const double* sp = sp_all + (size_t)b * SP_STRIDE;
   const double* alpha = alpha_all + (size_t)b * npad;
   const T* Kinv = Kinv_all + (size_t)b * sK;
   double* part = part_all + ((size_t)b * ntiles + blockIdx.x) * P;
-  const bool iso = cov_is_iso(cd.kind);
 
-  double r2[4][4];
+  // the 16 entries of K^-1 and the alpha values of this thread first: their latency hides under the
+  // distance sweep
+#ifndef GPC_TRACE_NOPREFETCH
+  T kin[4][4];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) r2[a][c] = 0.0;
-  for (int h0 = 0; h0 < cd.D; h0 += DCH) {
-    const int dc = min(DCH, cd.D - h0);
-    __syncthreads();
-    stage_x(xi, Xs, cd.D, i0, h0, dc, t);
-    stage_x(xj, Xs, cd.D, j0, h0, dc, t);
-    __syncthreads();
-    for (int h = 0; h < dc; ++h) {
-      double vi[4], vj[4];
+    for (int c = 0; c < 4; ++c) kin[a][c] = Kinv[(size_t)(i0 + ty + 16 * a) * ldk + j0 + tx + 16 * c];
+#endif
+  double r2[4][4];
+  tile_r2(r2, xi, xj, Xs, cd.D, i0, j0, t, tx, ty);
+  double al_i[4], al_j[4];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) vi[a] = xi[ty + 16 * a][h];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) vj[c] = xj[tx + 16 * c][h];
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const double d = vi[a] - vj[c];
-          r2[a][c] += d * d;
-        }
-    }
+  for (int a = 0; a < 4; ++a) {
+    al_i[a] = alpha[i0 + ty + 16 * a];
+    al_j[a] = alpha[j0 + tx + 16 * a];
   }
 
   const double sf2 = sp[SP_SF2], rqa = sp[SP_RQA], invsl = 1.0 / sp[SP_SL];
+  ExpC ex;
+  ex.load();
   double qF[4][4];
   double g_sf = 0.0, g_a = 0.0, g_iso = 0.0, trq = 0.0;
 #pragma unroll
@@ -241,31 +349,33 @@ __global__ __launch_bounds__(256) void trace_kernel(CovDesc cd, const double* __
       const bool valid = (i < n) && (j <= i);
       double qf = 0.0;
       if (valid) {
-        const double Q = (double)Kinv[(size_t)i * ldk + j] * invsl - alpha[i] * alpha[j];
+#ifndef GPC_TRACE_NOPREFETCH
+        const double kv = (double)kin[a][c];
+#else
+        const double kv = (double)Kinv[(size_t)i * ldk + j];
+#endif
+        const double Q = fma(kv, invsl, -al_i[a] * al_j[c]);
         const double qw = (i == j) ? Q : 2.0 * Q;
-        const PairVal pv = pair_eval(cd.kind, cd.degree, r2[a][c], sf2, rqa);
-        g_sf += qw * (2.0 * pv.K);
-        g_a += qw * pv.Ka;
+        const PairVal pv = pair_eval_t<KIND, DEG>(r2[a][c], sf2, rqa, ex);
+        g_sf = fma(qw, 2.0 * pv.K, g_sf);
+        if constexpr (KIND == K_RQ) g_a = fma(qw, pv.Ka, g_a);
         qf = qw * pv.F;
-        if (iso) g_iso += qf * r2[a][c];
+        if constexpr (ISO) g_iso = fma(qf, r2[a][c], g_iso);
         if (i == j) {
           trq += Q;
           diagQ_all[(size_t)b * npad + i] = Q;
         }
       }
-      qF[a][c] = qf;
+      qF[a][c] = qf;  // masked entries: exactly 0 (their d^2 is finite, so 0 * d^2 = 0); a valid
+                      // Matern-1 diagonal entry is +-inf and inf * 0 = NaN, as in the reference
     }
 
-  // per-wave sums into wpart[w][p]
-  auto put = [&](int p, double v) {
-    v = wave_sum(v);
-    if (lane == 0) wpart[w * P + p] = v;
-  };
-  if (iso) {
-    put(0, g_iso);
-    put(1, g_sf);
+  const int own = lane >> 4;  // which of the four values of a wave_sum4 this lane ends up holding
+  if constexpr (ISO) {
+    const double u = wave_sum4(g_iso, g_sf, trq, 0.0, lane);
+    if ((lane & 15) == 0 && own < 3) wpart[w * P4 + own] = u;  // slots 0, 1, 2 = P - 1
   } else {
-    // second sweep over the input dimensions: G_h = sum_e qF[e] * d_h[e]
+    // second sweep over the input dimensions, four at a time: G_h = sum_e qF[e] * d_h[e]^2
     for (int h0 = 0; h0 < cd.D; h0 += DCH) {
       const int dc = min(DCH, cd.D - h0);
       if (cd.D > DCH) {  // restage (single pass when D <= 32: LDS still holds it)
@@ -274,33 +384,59 @@ __global__ __launch_bounds__(256) void trace_kernel(CovDesc cd, const double* __
         stage_x(xj, Xs, cd.D, j0, h0, dc, t);
         __syncthreads();
       }
-      for (int h = 0; h < dc; ++h) {
-        double vi[4], vj[4];
+      for (int h = 0; h < dc; h += 4) {
+        double s4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int a = 0; a < 4; ++a) vi[a] = xi[ty + 16 * a][h];
+        for (int q = 0; q < 4; ++q) {
+          const int hh = h + q;
+          if (hh >= dc) break;  // block-uniform: the surplus slots of the last group stay 0 and are not stored
+          double vi[4], vj[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) vj[c] = xj[tx + 16 * c][h];
-        double s = 0.0;
+          for (int a = 0; a < 4; ++a) vi[a] = xi[ty + 16 * a][hh];
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+          for (int c = 0; c < 4; ++c) vj[c] = xj[tx + 16 * c][hh];
+          double s = 0.0;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const double d = vi[a] - vj[c];
-            // select, not multiply: a masked entry must not turn 0 * inf into NaN,
-            // a valid Matern-1 diagonal entry must (reference semantics).
-            s += (qF[a][c] != 0.0 || qF[a][c] != qF[a][c]) ? qF[a][c] * (d * d) : 0.0;
-          }
-        put(h0 + h, s);
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const double d = vi[a] - vj[c];
+              s = fma(qF[a][c] * d, d, s);
+            }
+          s4[q] = s;
+        }
+        const double u = wave_sum4(s4[0], s4[1], s4[2], s4[3], lane);
+        if ((lane & 15) == 0 && h + own < dc) wpart[w * P4 + h0 + h + own] = u;
       }
     }
-    put(cd.D, g_sf);
-    if (cd.kind == K_RQ) put(cd.D + 1, g_a);
+    const double u = wave_sum4(g_sf, g_a, trq, 0.0, lane);
+    if ((lane & 15) == 0) {
+      if (own == 0) wpart[w * P4 + cd.D] = u;
+      if (own == 1 && KIND == K_RQ) wpart[w * P4 + cd.D + 1] = u;
+      if (own == 2) wpart[w * P4 + P - 1] = u;
+    }
   }
-  put(P - 1, trq);
   __syncthreads();
   for (int p = t; p < P; p += 256)
-    part[p] = wpart[p] + wpart[P + p] + wpart[2 * P + p] + wpart[3 * P + p];
+    part[p] = wpart[p] + wpart[P4 + p] + wpart[2 * P4 + p] + wpart[3 * P4 + p];
 }
+
+// host-side dispatch on (kernel family, degree): one template instance per combination
+#define GPC_COV_DISPATCH(KERNEL, T, cd, grid, block, shm, st, ...)                                            \
+  do {                                                                                                      \
+    switch ((cd).kind * 8 + ((cd).kind == K_MATERN || (cd).kind == K_MATERN_ISO ? (cd).degree : 0)) {      \
+      case K_SE * 8: hipLaunchKernelGGL((KERNEL<T, K_SE, 0>), grid, block, shm, st, __VA_ARGS__); break;    \
+      case K_RQ * 8: hipLaunchKernelGGL((KERNEL<T, K_RQ, 0>), grid, block, shm, st, __VA_ARGS__); break;    \
+      case K_SE_ISO * 8: hipLaunchKernelGGL((KERNEL<T, K_SE_ISO, 0>), grid, block, shm, st, __VA_ARGS__); break; \
+      case K_MATERN * 8 + 1: hipLaunchKernelGGL((KERNEL<T, K_MATERN, 1>), grid, block, shm, st, __VA_ARGS__); break; \
+      case K_MATERN * 8 + 3: hipLaunchKernelGGL((KERNEL<T, K_MATERN, 3>), grid, block, shm, st, __VA_ARGS__); break; \
+      case K_MATERN * 8 + 5: hipLaunchKernelGGL((KERNEL<T, K_MATERN, 5>), grid, block, shm, st, __VA_ARGS__); break; \
+      case K_MATERN_ISO * 8 + 1: hipLaunchKernelGGL((KERNEL<T, K_MATERN_ISO, 1>), grid, block, shm, st, __VA_ARGS__); break; \
+      case K_MATERN_ISO * 8 + 3: hipLaunchKernelGGL((KERNEL<T, K_MATERN_ISO, 3>), grid, block, shm, st, __VA_ARGS__); break; \
+      case K_MATERN_ISO * 8 + 5: hipLaunchKernelGGL((KERNEL<T, K_MATERN_ISO, 5>), grid, block, shm, st, __VA_ARGS__); break; \
+      default: break;                                                                                       \
+    }                                                                                                       \
+  } while (0)
 
 // out[b][p] = sum_tile part[b][tile][p]  in a fixed order.  grid = (P, batch)
 __global__ __launch_bounds__(256) void reduce_parts_kernel(const double* __restrict__ part, int ntiles,

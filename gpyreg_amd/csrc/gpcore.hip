@@ -428,8 +428,9 @@ struct Pipe {
                          c->mulb.as<double>() + (size_t)off * D, c->divb.as<double>() + (size_t)off * D, xs);
     }
     const int t64 = npad / CT, ntl = t64 * (t64 + 1) / 2;
-    hipLaunchKernelGGL((build_kernel<T>), dim3(ntl, n), dim3(256), 0, st, b.cd, (const double*)xs,
-                       (const double*)spb, c->dvec.as<double>() + (size_t)off * npad, N, npad, Ac, sM, npad);
+    GPC_COV_DISPATCH(build_kernel, T, b.cd, dim3(ntl, n), dim3(256), 0, st, b.cd, (const double*)xs,
+                     (const double*)spb, (const double*)(c->dvec.as<double>() + (size_t)off * npad), N, npad, Ac, sM,
+                     npad);
     HIPCHK(c, hipGetLastError());
 
     if (f0 && !c->capturing) HIPCHK(c, hipEventRecord(f0, st));
@@ -482,9 +483,9 @@ struct Pipe {
     if (mode == MODE_GRAD) {
       double* parts = c->parts.as<double>() + (size_t)off * ntl * Pn;
       double* diagq = c->diagq.as<double>() + (size_t)off * npad;
-      hipLaunchKernelGGL((trace_kernel<T>), dim3(ntl, n), dim3(256), 4 * Pn * sizeof(double), st, b.cd,
-                         (const double*)xs, (const double*)spb, (const double*)avec, N, npad, (const T*)Tc, sM,
-                         npad, parts, ntl, diagq);
+      GPC_COV_DISPATCH(trace_kernel, T, b.cd, dim3(ntl, n), dim3(256), 4 * (((Pn + 3) & ~3) + 4) * sizeof(double), st,
+                       b.cd, (const double*)xs, (const double*)spb, (const double*)avec, N, npad, (const T*)Tc, sM,
+                       npad, parts, ntl, diagq);
       hipLaunchKernelGGL(reduce_parts_kernel, dim3(Pn, n), dim3(256), 0, st, (const double*)parts, ntl, Pn,
                          c->gout.as<double>() + (size_t)off * Pn);
       if (mean_N > 0)

@@ -452,8 +452,13 @@ __device__ __forceinline__ void leaf3_panel(typename MM<T>::acc_t (&S)[2][8], T*
   }
 }
 
+// GPC_LEAF3_WPS = waves per SIMD the register allocation allows for: 2 caps the leaf at 256 registers so
+// that a leaf block fits on a CU BESIDE one resident 128-tile GEMM block (240 VGPRs, 72 KB LDS).
+#ifndef GPC_LEAF3_WPS
+#define GPC_LEAF3_WPS 1
+#endif
 template <typename T>
-__global__ __launch_bounds__(256) void leaf3_kernel(T* __restrict__ A, long long sA, int lda,
+__global__ __launch_bounds__(256, GPC_LEAF3_WPS) void leaf3_kernel(T* __restrict__ A, long long sA, int lda,
                                                     T* __restrict__ W, long long sW, int ldw, int off,
                                                     double* __restrict__ logdet, int* __restrict__ info,
                                                     int nvalid) {
