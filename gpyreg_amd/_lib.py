@@ -47,6 +47,14 @@ SIGNATURES = {
         C.c_int,
         [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, C.POINTER(_vp), _dp, _ip, _ip],
     ),
+    "gpc_nll_batch_K": (
+        C.c_int,
+        [_vp, C.c_int, C.c_int, C.c_int, _dp, _vp, _vp, _dp, _dp, C.c_int, C.c_int, _dp, C.c_int, _dp,
+         C.c_int, _dp, _dp, _dp, _ip, _ip],
+    ),
+    "gpc_posterior_batch_K": (
+        C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, C.POINTER(_vp), _dp, _ip, _ip]),
+    "gpc_predict_K": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp, _dp]),
     "gpc_post_fetch": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
     "gpc_post_free": (C.c_int, [_vp]),
     "gpc_predict": (C.c_int, [_vp, _dp, C.c_int, _dp, _dp]),
@@ -66,6 +74,9 @@ SIGNATURES = {
     "gpc_debug_leaf": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp, _ip]),
     "gpc_debug_factor": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip]),
 }
+
+# int (*gpc_dk_plane_fn)(void* user, int sample, int p, double* plane)
+DK_PLANE_FN = C.CFUNCTYPE(C.c_int, _vp, C.c_int, C.c_int, _dp)
 
 _lib = None
 _lock = threading.Lock()
@@ -188,6 +199,62 @@ class Context:
         self._check(rc, "gpc_nll_batch")
         return nlz, dnlz, mult, lchol.astype(bool), info
 
+    def nll_batch_K(self, dtype, K, dK_plane, cov_N, m, sn2, sn2_is_vector, want_grad=False, dm=None,
+                    dsn2=None):
+        """gpc_nll_batch_K: K (S,N,N) from the caller's covariance object; ``dK_plane(s, p)`` returns
+        the (N,N) array dK[:, :, p] of sample s (called once per sample and hyperparameter)."""
+        K = _f64(K)
+        m = _f64(m)
+        sn2 = _f64(sn2)
+        S, N = K.shape[0], K.shape[1]
+        vec = 1 if sn2_is_vector else 0
+        if K.shape != (S, self.N, self.N) or sn2.shape != (S, self.N if vec else 1) or m.shape != (S, self.N):
+            raise ValueError("K must be (S,N,N); m (S,N); sn2 (S,N) when per-point, else (S,1)")
+        mean_N = 0 if dm is None else dm.shape[2]
+        noise_N = 0 if dsn2 is None else dsn2.shape[2]
+        dm_c = None if dm is None or mean_N == 0 else _f64(dm)
+        dsn2_c = None if dsn2 is None or noise_N == 0 else _f64(dsn2)
+        hyp_N = cov_N + noise_N + mean_N
+        nlz = np.empty(S)
+        dnlz = np.empty((S, hyp_N)) if want_grad else None
+        mult = np.empty(S)
+        lchol = np.empty(S, dtype=np.int32)
+        info = np.empty(S, dtype=np.int32)
+        err = []
+
+        def plane_cb(_user, s, p, out):
+            try:
+                np.ctypeslib.as_array(out, shape=(N, N))[...] = dK_plane(s, p)
+                return 0
+            except Exception as e:  # noqa: BLE001 - reported through the return code, re-raised below
+                err.append(e)
+                return 1
+
+        cb = DK_PLANE_FN(plane_cb)
+        rc = self._lib.gpc_nll_batch_K(
+            self._h, dtype, S, cov_N, _ptr(K), C.cast(cb, _vp) if want_grad else None, None, _ptr(m),
+            _ptr(sn2), vec, 1 if want_grad else 0, _ptr(dm_c), mean_N, _ptr(dsn2_c), noise_N, _ptr(nlz),
+            _ptr(dnlz), _ptr(mult), lchol.ctypes.data_as(_ip), info.ctypes.data_as(_ip))
+        if err:
+            raise err[0]
+        self._check(rc, "gpc_nll_batch_K")
+        return nlz, dnlz, mult, lchol.astype(bool), info
+
+    def posterior_batch_K(self, dtype, K, m, sn2, sn2_is_vector):
+        K, m, sn2 = _f64(K), _f64(m), _f64(sn2)
+        S = K.shape[0]
+        vec = 1 if sn2_is_vector else 0
+        if K.shape != (S, self.N, self.N) or sn2.shape != (S, self.N if vec else 1) or m.shape != (S, self.N):
+            raise ValueError("K must be (S,N,N); m (S,N); sn2 (S,N) when per-point, else (S,1)")
+        mult = np.empty(S)
+        lchol = np.empty(S, dtype=np.int32)
+        info = np.empty(S, dtype=np.int32)
+        h = _vp()
+        rc = self._lib.gpc_posterior_batch_K(self._h, dtype, S, _ptr(K), _ptr(m), _ptr(sn2), vec, C.byref(h),
+                                             _ptr(mult), lchol.ctypes.data_as(_ip), info.ctypes.data_as(_ip))
+        self._check(rc, "gpc_posterior_batch_K")
+        return PostHandle(self, h, S, self.N), mult, lchol.astype(bool), info
+
     def posterior_batch(self, kid, degree, dtype, hyp_cov, m, sn2, sn2_is_vector):
         hyp_cov = _f64(hyp_cov)
         m = _f64(m)
@@ -274,6 +341,19 @@ class PostHandle:
         rc = self.ctx._lib.gpc_predict(self._h, _ptr(xs), M, _ptr(fmu), _ptr(fs2))
         self.ctx._check(rc, "gpc_predict")
         return fmu, fs2
+
+    def predict_K(self, Ks, Kss=None, want_var=True):
+        """gpc_predict_K: Ks (S,N,M) caller-provided cross covariances; returns fmu (M,S), the
+        variance term fq (M,S; add kss) and, with Kss (S,M,M), the full covariances (S,M,M)."""
+        Ks = _f64(Ks)
+        M = Ks.shape[2]
+        fmu = np.empty((M, self.S))
+        fq = np.empty((M, self.S)) if want_var else None
+        Kss_c = None if Kss is None else _f64(Kss)
+        cov = None if Kss is None else np.empty((self.S, M, M))
+        rc = self.ctx._lib.gpc_predict_K(self._h, M, _ptr(Ks), _ptr(Kss_c), _ptr(fmu), _ptr(fq), _ptr(cov))
+        self.ctx._check(rc, "gpc_predict_K")
+        return fmu, fq, cov
 
     def append(self, m_star, sn2_star, y_new):
         """Rank-one append of the point already added to the context's data.  Returns the

@@ -316,6 +316,77 @@ __global__ void append_low_kernel(T* __restrict__ A, int ld, int n, const double
   if (j == 0 && i < n) alpha[i] += ca * au[i];
 }
 
+// ---- caller-provided covariance (gpc_nll_batch_K / gpc_posterior_batch_K / gpc_predict_K) ----
+// A (npad x npad, identity padding) = K / sp[2] + diag(dvec)   from a dense n x n double matrix
+// (sp[2] = SP_KSCALE: gaussian_process.py:2416 / :2432).   grid = (npad/64, npad/4), block = (64, 4)
+template <typename T>
+__global__ void load_K_kernel(const double* __restrict__ K, int n, int npad, const double* __restrict__ sp,
+                              const double* __restrict__ dvec, T* __restrict__ A) {
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  const int i = blockIdx.y * 4 + threadIdx.y;
+  if (i >= npad || j >= npad) return;
+  double v = (i == j) ? 1.0 : 0.0;
+  if (i < n && j < n) {
+    v = K[(size_t)i * n + j] / sp[2];
+    if (i == j) v += dvec[i];
+  }
+  A[(size_t)i * npad + j] = (T)v;
+}
+
+// dst (rpad x cpad, zero padding) = (T) src (r x c doubles).   grid = (cpad/64, rpad/4), block = (64, 4)
+template <typename T>
+__global__ void pad_rect_kernel(const double* __restrict__ src, int r, int c, int rpad, int cpad,
+                                T* __restrict__ dst) {
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  const int i = blockIdx.y * 4 + threadIdx.y;
+  if (i >= rpad || j >= cpad) return;
+  dst[(size_t)i * cpad + j] = (T)((i < r && j < c) ? src[(size_t)i * c + j] : 0.0);
+}
+
+// diagQ[b][i] = Ainv[b][i][i] / sl - alpha_i^2 and out[b * P + P - 1] = trace(Q)  (sp[3] = SP_SL).
+// grid = (1, batch), 256 threads
+template <typename T>
+__global__ __launch_bounds__(256) void diagq_kernel(const T* __restrict__ Ainv_all, long long sA, int ld,
+                                                    const double* __restrict__ alpha_all,
+                                                    const double* __restrict__ sp_all, int n,
+                                                    double* __restrict__ diagq_all, double* __restrict__ out, int P) {
+  __shared__ double sh4[4];
+  const int b = blockIdx.y;
+  const T* Ainv = Ainv_all + (size_t)b * sA;
+  const double* alpha = alpha_all + (size_t)b * ld;
+  const double invsl = 1.0 / sp_all[(size_t)b * 4 + 3];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const double q = (double)Ainv[(size_t)i * ld + i] * invsl - alpha[i] * alpha[i];
+    diagq_all[(size_t)b * ld + i] = q;
+    s += q;
+  }
+  s = block_sum_256(s, sh4);
+  if (threadIdx.x == 0) out[(size_t)b * P + P - 1] = s;
+}
+
+// part[block] = sum over this block's entries of Q_ij * dK_ij, Q = Ainv / sl - alpha alpha^T taken from the
+// LOWER triangle of Ainv (Q is symmetric), dK a dense n x n plane (gaussian_process.py:2487-2488: the
+// reference sums the full matrices).  Fixed grid-stride assignment: deterministic.  grid = (nblk), 256 threads
+template <typename T>
+__global__ __launch_bounds__(256) void trace_plane_kernel(const T* __restrict__ Ainv, int ld,
+                                                          const double* __restrict__ alpha,
+                                                          const double* __restrict__ sp,
+                                                          const double* __restrict__ dK, int n,
+                                                          double* __restrict__ part) {
+  __shared__ double sh4[4];
+  const double invsl = 1.0 / sp[3];
+  const long long tot = (long long)n * n;
+  double s = 0.0;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < tot; idx += (long long)gridDim.x * 256) {
+    const int i = (int)(idx / n), j = (int)(idx - (long long)i * n);
+    const double a = (double)(j <= i ? Ainv[(size_t)i * ld + j] : Ainv[(size_t)j * ld + i]);
+    s += (a * invsl - alpha[i] * alpha[j]) * dK[idx];
+  }
+  s = block_sum_256(s, sh4);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
 // independent-chain VALU FMA loop (what the non-MFMA kernels are bounded by)
 template <typename T>
 __global__ __launch_bounds__(256) void valu_peak_kernel(T* out, int iters, long long* clk) {

@@ -331,9 +331,10 @@ struct Batch {
     tries.assign(S, 0);
     info.assign(S, 0);
     for (int s = 0; s < S; ++s) {
-      double sf2, rqa;
-      scaling_of(cd.kind, cd.degree, D, hyp_cov + (size_t)s * cd.cov_N, &mul[(size_t)s * D],
-                 &dv[(size_t)s * D], &sf2, &rqa);
+      double sf2 = 0.0, rqa = 1.0;
+      if (hyp_cov)  // built-in kernel; with a caller-provided K (cd.kind < 0) there is nothing to scale
+        scaling_of(cd.kind, cd.degree, D, hyp_cov + (size_t)s * cd.cov_N, &mul[(size_t)s * D],
+                   &dv[(size_t)s * D], &sf2, &rqa);
       sp[(size_t)s * SP_STRIDE + SP_SF2] = sf2;
       sp[(size_t)s * SP_STRIDE + SP_RQA] = rqa;
       const double* sn = sn2 + (size_t)s * (vec_noise ? N : 1);
@@ -402,8 +403,42 @@ struct Pipe {
   int noise_N = 0;
   // outputs (whole batch, host)
   std::vector<double> logdet, quad, G, mg, ng;
+  // caller-provided covariance ("K-mode", gpc_nll_batch_K / gpc_posterior_batch_K): host pointer to the
+  // N x N matrix of every sample of the batch, and the callback that delivers dK one plane at a time
+  std::vector<const double*> Kptr;
+  gpc_dk_plane_fn dk_cb = nullptr;
+  void* dk_user = nullptr;
+  std::vector<int> orig;  // index of each sample in the caller's numbering (for the callback)
+  bool kmode() const { return !Kptr.empty(); }
 
   int P() const { return B->cd.cov_N + 1; }
+
+  // K-mode: sum_ij Q_ij dK_ij/dtheta_p for the sample in workspace slot `slot`, one plane at a time
+  // (the caller's compute() produced dK on the host; only one N x N plane is ever resident here).
+  int trace_planes(int s, int slot) {
+    Batch& b = *B;
+    const int N = b.N, npad = b.npad, cov_N = b.cd.cov_N, Pn = P();
+    hipStream_t st = c->st;
+    const size_t pb = (size_t)N * N * sizeof(double);
+    HIPCHK(c, c->dbg1.ensure(pb));
+    const int nblk = (int)std::min<long long>(1024, ((long long)N * N + 255) / 256);
+    HIPCHK(c, c->dbg2.ensure((size_t)nblk * sizeof(double) + 64));
+    std::vector<double> plane((size_t)N * N);
+    for (int p = 0; p < cov_N; ++p) {
+      if (dk_cb(dk_user, orig.empty() ? s : orig[s], p, plane.data()) != 0) FAIL(c, "the dK callback reported an error");
+      HIPCHK(c, hipMemcpyAsync(c->dbg1.p, plane.data(), pb, hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL((trace_plane_kernel<T>), dim3(nblk), dim3(256), 0, st, (const T*)(Tm + (size_t)slot * sM), npad,
+                         (const double*)(c->avec.as<double>() + (size_t)slot * npad),
+                         (const double*)(c->spb.as<double>() + (size_t)slot * SP_STRIDE), c->dbg1.as<double>(), N,
+                         c->dbg2.as<double>());
+      hipLaunchKernelGGL(reduce_parts_kernel, dim3(1, 1), dim3(256), 0, st, (const double*)c->dbg2.p, nblk, 1,
+                         c->dbg2.as<double>() + nblk);
+      HIPCHK(c, hipGetLastError());
+      HIPCHK(c, hipMemcpyAsync(&G[(size_t)s * Pn + p], c->dbg2.as<double>() + nblk, 8, hipMemcpyDeviceToHost, st));
+      HIPCHK(c, hipStreamSynchronize(st));  // `plane` is reused for the next hyperparameter
+    }
+    return 0;
+  }
 
   // Device kernels for `n` samples of the current chunk starting at chunk index `off`
   // (all per-sample buffers are indexed by chunk position), issued on stream `st`.
@@ -421,16 +456,28 @@ struct Pipe {
     double* d_logdet = c->scal.as<double>() + off;
     double* d_quad = c->scal.as<double>() + chunk_cnt + off;
     int* d_info = reinterpret_cast<int*>(c->scal.as<double>() + 2 * chunk_cnt) + off;
-    {
+    const int t64 = npad / CT, ntl = t64 * (t64 + 1) / 2;
+    if (kmode()) {
+      // A = K / (sn2_div * sn2_mult) + diag from the caller's matrix, one sample at a time through one
+      // N x N staging buffer (stream order keeps the upload of sample i+1 behind the kernel reading i)
+      HIPCHK(c, c->dbg1.ensure((size_t)N * N * sizeof(double)));
+      for (int i = 0; i < n; ++i) {
+        HIPCHK(c, hipMemcpyAsync(c->dbg1.p, Kptr[chunk_s0 + off + i], (size_t)N * N * sizeof(double),
+                                 hipMemcpyHostToDevice, st));
+        dim3 gl(npad / 64, npad / 4), bl(64, 4);
+        hipLaunchKernelGGL((load_K_kernel<T>), gl, bl, 0, st, (const double*)c->dbg1.p, N, npad,
+                           (const double*)(spb + (size_t)i * SP_STRIDE),
+                           (const double*)(c->dvec.as<double>() + (size_t)(off + i) * npad), Ac + (size_t)i * sM);
+      }
+    } else {
       const long long tot = (long long)npad * D;
       dim3 grid((unsigned)((tot + 255) / 256), n);
       hipLaunchKernelGGL(scale_x_kernel, grid, dim3(256), 0, st, c->dX.as<double>(), N, npad, D,
                          c->mulb.as<double>() + (size_t)off * D, c->divb.as<double>() + (size_t)off * D, xs);
+      GPC_COV_DISPATCH(build_kernel, T, b.cd, dim3(ntl, n), dim3(256), 0, st, b.cd, (const double*)xs,
+                       (const double*)spb, (const double*)(c->dvec.as<double>() + (size_t)off * npad), N, npad, Ac, sM,
+                       npad);
     }
-    const int t64 = npad / CT, ntl = t64 * (t64 + 1) / 2;
-    GPC_COV_DISPATCH(build_kernel, T, b.cd, dim3(ntl, n), dim3(256), 0, st, b.cd, (const double*)xs,
-                     (const double*)spb, (const double*)(c->dvec.as<double>() + (size_t)off * npad), N, npad, Ac, sM,
-                     npad);
     HIPCHK(c, hipGetLastError());
 
     if (f0 && !c->capturing) HIPCHK(c, hipEventRecord(f0, st));
@@ -483,11 +530,17 @@ struct Pipe {
     if (mode == MODE_GRAD) {
       double* parts = c->parts.as<double>() + (size_t)off * ntl * Pn;
       double* diagq = c->diagq.as<double>() + (size_t)off * npad;
-      GPC_COV_DISPATCH(trace_kernel, T, b.cd, dim3(ntl, n), dim3(256), 4 * (((Pn + 3) & ~3) + 4) * sizeof(double), st,
-                       b.cd, (const double*)xs, (const double*)spb, (const double*)avec, N, npad, (const T*)Tc, sM,
-                       npad, parts, ntl, diagq);
-      hipLaunchKernelGGL(reduce_parts_kernel, dim3(Pn, n), dim3(256), 0, st, (const double*)parts, ntl, Pn,
-                         c->gout.as<double>() + (size_t)off * Pn);
+      if (kmode()) {
+        // diag(Q) and trace(Q) now; the covariance slots are filled plane by plane after the sync (trace_planes)
+        hipLaunchKernelGGL((diagq_kernel<T>), dim3(1, n), dim3(256), 0, st, (const T*)Tc, sM, npad, (const double*)avec,
+                           (const double*)spb, N, diagq, c->gout.as<double>() + (size_t)off * Pn, Pn);
+      } else {
+        GPC_COV_DISPATCH(trace_kernel, T, b.cd, dim3(ntl, n), dim3(256), 4 * (((Pn + 3) & ~3) + 4) * sizeof(double), st,
+                         b.cd, (const double*)xs, (const double*)spb, (const double*)avec, N, npad, (const T*)Tc, sM,
+                         npad, parts, ntl, diagq);
+        hipLaunchKernelGGL(reduce_parts_kernel, dim3(Pn, n), dim3(256), 0, st, (const double*)parts, ntl, Pn,
+                           c->gout.as<double>() + (size_t)off * Pn);
+      }
       if (mean_N > 0)
         hipLaunchKernelGGL(mat_t_vec_kernel, dim3(mean_N, n), dim3(256), 0, st,
                            (const double*)(c->dmb.as<double>() + (size_t)off * N * mean_N), N, mean_N,
@@ -554,6 +607,7 @@ struct Pipe {
   }
 
   int chunk_cnt = 0;
+  int chunk_s0 = 0;  // first sample (batch numbering) of the chunk being processed
   int lauum_n[gpc_ctx::MAXG + 1] = {};
 
   // run the device pipeline for samples [s0, s0+cnt) whose matrices start at slot `slot`.
@@ -568,6 +622,7 @@ struct Pipe {
     const int t64 = npad / CT, ntl = t64 * (t64 + 1) / 2;
     const int Pn = P();
     chunk_cnt = cnt;
+    chunk_s0 = s0;
     // the pipe's matrix pointers are relative to chunk position 0
     T* A0 = A;
     T* W0 = W;
@@ -625,8 +680,8 @@ struct Pipe {
 
     hc.lap("h2d");
     int groups = c->groups;
-    if (cnt < 2 * groups || npad < 1024) groups = 1;
-    if (groups == 1 && c->graph_max_npad > 0 && npad <= c->graph_max_npad) {
+    if (cnt < 2 * groups || npad < 1024 || kmode()) groups = 1;
+    if (groups == 1 && c->graph_max_npad > 0 && npad <= c->graph_max_npad && !kmode()) {
       int rc = graph_section(cnt);
       if (rc) return rc;
     } else if (groups == 1) {
@@ -669,6 +724,12 @@ struct Pipe {
     HIPCHK(c, hipStreamSynchronize(st));
     hc.lap("d2h+sync");
     for (int i = 0; i < cnt; ++i) b.info[s0 + i] = hinfo[i];
+    if (kmode() && mode == MODE_GRAD)
+      for (int i = 0; i < cnt; ++i)
+        if (hinfo[i] == 0) {
+          int rc = trace_planes(s0 + i, slot + i);
+          if (rc) return rc;
+        }
     float t03 = 0, t12 = 0;
     (void)hipEventElapsedTime(&t03, c->ev[0], c->ev[3]);
     (void)hipEventElapsedTime(&t12, c->ev[1], c->ev[2]);
@@ -716,19 +777,19 @@ struct Pipe {
       sb.cd = b.cd;
       sb.vec_noise = b.vec_noise;
       sb.y = b.y;
-      std::vector<double> hc((size_t)nf * cov_N), mm((size_t)nf * N), sn((size_t)nf * nsn), gdm, gds;
+      std::vector<double> hc(b.hyp_cov ? (size_t)nf * cov_N : 0), mm((size_t)nf * N), sn((size_t)nf * nsn), gdm, gds;
       const bool gm = mode == MODE_GRAD && mean_N > 0, gn = mode == MODE_GRAD && noise_N > 0 && b.vec_noise;
       if (gm) gdm.resize((size_t)nf * N * mean_N);
       if (gn) gds.resize((size_t)nf * N * noise_N);
       for (int i = 0; i < nf; ++i) {
         const int s = fail[i];
-        std::copy_n(b.hyp_cov + (size_t)s * cov_N, cov_N, &hc[(size_t)i * cov_N]);
+        if (b.hyp_cov) std::copy_n(b.hyp_cov + (size_t)s * cov_N, cov_N, &hc[(size_t)i * cov_N]);
         std::copy_n(b.m + (size_t)s * N, N, &mm[(size_t)i * N]);
         std::copy_n(b.sn2 + (size_t)s * nsn, nsn, &sn[(size_t)i * nsn]);
         if (gm) std::copy_n(dm + (size_t)s * N * mean_N, (size_t)N * mean_N, &gdm[(size_t)i * N * mean_N]);
         if (gn) std::copy_n(dsn2 + (size_t)s * N * noise_N, (size_t)N * noise_N, &gds[(size_t)i * N * noise_N]);
       }
-      sb.hyp_cov = hc.data();
+      sb.hyp_cov = b.hyp_cov ? hc.data() : nullptr;
       sb.m = mm.data();
       sb.sn2 = sn.data();
       sb.init();
@@ -752,6 +813,14 @@ struct Pipe {
       q.mean_N = mean_N;
       q.dsn2 = gn ? gds.data() : dsn2;
       q.noise_N = noise_N;
+      if (kmode()) {
+        q.dk_cb = dk_cb;
+        q.dk_user = dk_user;
+        for (int i = 0; i < nf; ++i) {
+          q.Kptr.push_back(Kptr[fail[i]]);
+          q.orig.push_back(orig.empty() ? fail[i] : orig[fail[i]]);
+        }
+      }
       q.logdet.assign(nf, 0.0);
       q.quad.assign(nf, 0.0);
       q.G.assign((size_t)nf * Pn, 0.0);
@@ -793,9 +862,24 @@ size_t free_device_bytes() {
   return f;
 }
 
+// caller-provided covariance matrices (K-mode): S matrices of N x N doubles, and the dK plane callback
+struct KArgs {
+  const double* K = nullptr;
+  gpc_dk_plane_fn cb = nullptr;
+  void* user = nullptr;
+};
+template <typename PipeT>
+void set_kmode(PipeT& p, const KArgs* km, int S, int N) {
+  if (!km) return;
+  for (int s = 0; s < S; ++s) p.Kptr.push_back(km->K + (size_t)s * N * N);
+  p.dk_cb = km->cb;
+  p.dk_user = km->user;
+}
+
 template <typename T>
 int nll_impl(gpc_ctx* c, Batch& b, int want_grad, const double* dm, int mean_N, const double* dsn2,
-             int noise_N, double* nlz, double* dnlz, double* sn2_mult, int* L_chol, int* info) {
+             int noise_N, double* nlz, double* dnlz, double* sn2_mult, int* L_chol, int* info,
+             const KArgs* km = nullptr) {
   const int S = b.S, npad = b.npad, N = b.N;
   const size_t per = 3ull * npad * npad * sizeof(T);
   int chunk = S;
@@ -825,6 +909,7 @@ int nll_impl(gpc_ctx* c, Batch& b, int want_grad, const double* dm, int mean_N, 
   p.mean_N = mean_N;
   p.dsn2 = dsn2;
   p.noise_N = noise_N;
+  set_kmode(p, km, S, N);
   const int Pn = p.P();
   p.logdet.assign(S, 0.0);
   p.quad.assign(S, 0.0);
@@ -870,7 +955,7 @@ int nll_impl(gpc_ctx* c, Batch& b, int want_grad, const double* dm, int mean_N, 
 int check_batch_args(gpc_ctx* c, int kernel_id, int degree, int dtype, int S) {
   if (!c) return -2;
   if (c->N <= 0) FAIL(c, "gpc_set_data has not been called");
-  if (!valid_kernel(kernel_id, degree)) FAIL(c, "unknown covariance kernel / degree");
+  if (kernel_id != -1 && !valid_kernel(kernel_id, degree)) FAIL(c, "unknown covariance kernel / degree");
   if (dtype != GPC_F64 && dtype != GPC_F32) FAIL(c, "dtype must be GPC_F64 or GPC_F32");
   if (S <= 0) FAIL(c, "S must be positive");
   if (c->N > gpc_max_n(dtype))
@@ -888,7 +973,7 @@ void fill_batch(gpc_ctx* c, Batch& b, int kernel_id, int degree, int S, const do
   b.cd.kind = kernel_id;
   b.cd.degree = degree;
   b.cd.D = c->D;
-  b.cd.cov_N = cov_count_of(kernel_id, c->D);
+  b.cd.cov_N = kernel_id < 0 ? degree : cov_count_of(kernel_id, c->D);  // K-mode: `degree` carries cov_N
   b.vec_noise = vec != 0;
   b.hyp_cov = hyp_cov;
   b.m = m;
@@ -899,7 +984,8 @@ void fill_batch(gpc_ctx* c, Batch& b, int kernel_id, int degree, int S, const do
 }
 
 template <typename T>
-int post_impl(gpc_ctx* c, Batch& b, gpc_post* po, double* sn2_mult, int* L_chol, int* info) {
+int post_impl(gpc_ctx* c, Batch& b, gpc_post* po, double* sn2_mult, int* L_chol, int* info,
+              const KArgs* km = nullptr) {
   const int S = b.S, npad = b.npad;
   const size_t msz = (size_t)npad * npad * sizeof(T);
   HostClock hc("post");
@@ -925,6 +1011,7 @@ int post_impl(gpc_ctx* c, Batch& b, gpc_post* po, double* sn2_mult, int* L_chol,
   p.B = &b;
   p.mode = MODE_POST;
   p.sM = (long long)npad * npad;
+  set_kmode(p, km, S, b.N);
   p.logdet.assign(S, 0.0);
   p.quad.assign(S, 0.0);
   c->ms_total = c->ms_factor = 0;
@@ -1040,8 +1127,10 @@ int rhs_products(gpc_post* po, int mode, const double* xa, const double* xb, int
   double* d_xa = c->xss.as<double>() + (size_t)chunk * mpad * D;
   double* d_xb = d_xa + (size_t)M * D;
   c->pin.begin();
-  HIPCHK(c, c->pin.up(d_xa, xa, (size_t)M * D * 8, st));
-  if (xb) HIPCHK(c, c->pin.up(d_xb, xb, (size_t)M * D * 8, st));
+  if (mode != 2) {
+    HIPCHK(c, c->pin.up(d_xa, xa, (size_t)M * D * 8, st));
+    if (xb) HIPCHK(c, c->pin.up(d_xb, xb, (size_t)M * D * 8, st));
+  }
   // landing buffers of the per-chunk results (pinned when available)
   std::vector<double> hmu_v, hv_v;
   double* hmu = static_cast<double*>(c->pin.alloc((size_t)chunk * mpad * 8));
@@ -1081,6 +1170,19 @@ int rhs_products(gpc_post* po, int mode, const double* xa, const double* xb, int
         hipLaunchKernelGGL((cross_kernel<T>), dim3(mpad / 64, mpad / 4, cnt), dim3(64, 4), 0, st, po->cd,
                            c->xss.as<double>(), c->xss.as<double>(), c->spb.as<double>(), M, mpad, M, mpad,
                            c->kss.as<T>(), sKss);
+    } else if (mode == 2) {
+      // caller-provided cross covariances Ks_s (N x M doubles, xa) and, with `full`, K**_s (M x M, xb)
+      HIPCHK(c, c->dbg1.ensure((size_t)std::max(N, M) * M * sizeof(double)));
+      for (int i = 0; i < cnt; ++i) {
+        HIPCHK(c, hipMemcpyAsync(c->dbg1.p, xa + (size_t)(s0 + i) * N * M, (size_t)N * M * 8, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL((pad_rect_kernel<T>), dim3(mpad / 64, npad / 4), dim3(64, 4), 0, st, (const double*)c->dbg1.p, N,
+                           M, npad, mpad, Ks + (size_t)i * sKs);
+        if (full) {
+          HIPCHK(c, hipMemcpyAsync(c->dbg1.p, xb + (size_t)(s0 + i) * M * M, (size_t)M * M * 8, hipMemcpyHostToDevice, st));
+          hipLaunchKernelGGL((pad_rect_kernel<T>), dim3(mpad / 64, mpad / 4), dim3(64, 4), 0, st, (const double*)c->dbg1.p,
+                             M, M, mpad, mpad, c->kss.as<T>() + (size_t)i * sKss);
+        }
+      }
     } else {
       hipLaunchKernelGGL((quad_z_kernel<T>), dim3(mpad / 64, npad / 4, cnt), dim3(64, 4), 0, st,
                          c->dX.as<double>(), (const double*)d_xa, (const double*)d_xb, c->mulb.as<double>(),
@@ -1677,6 +1779,74 @@ int gpc_posterior_batch(gpc_ctx* c, int kernel_id, int degree, int dtype, int S,
   return 0;
 }
 
+int gpc_nll_batch_K(gpc_ctx* c, int dtype, int S, int cov_N, const double* K, gpc_dk_plane_fn dk_plane, void* user,
+                    const double* m, const double* sn2, int sn2_is_vector, int want_grad, const double* dm,
+                    int mean_N, const double* dsn2, int noise_N, double* nlz, double* dnlz, double* sn2_mult,
+                    int* L_chol, int* info) {
+  int rc = check_batch_args(c, -1, 0, dtype, S);
+  if (rc) return rc;
+  if (!K || !m || !sn2 || !nlz || !sn2_mult || !L_chol || !info || cov_N < 0) FAIL(c, "gpc_nll_batch_K: bad argument");
+  if (want_grad && (!dnlz || (cov_N > 0 && !dk_plane) || (mean_N > 0 && !dm) || (noise_N > 0 && !dsn2)))
+    FAIL(c, "gpc_nll_batch_K: gradient requested without dnlz / dK callback / dm / dsn2");
+  HIPCHK(c, hipSetDevice(c->device));
+  Batch b;
+  fill_batch(c, b, -1, cov_N, S, nullptr, m, sn2, sn2_is_vector);
+  KArgs km{K, dk_plane, user};
+  if (dtype == GPC_F64)
+    return nll_impl<double>(c, b, want_grad, dm, mean_N, dsn2, noise_N, nlz, dnlz, sn2_mult, L_chol, info, &km);
+  return nll_impl<float>(c, b, want_grad, dm, mean_N, dsn2, noise_N, nlz, dnlz, sn2_mult, L_chol, info, &km);
+}
+
+int gpc_posterior_batch_K(gpc_ctx* c, int dtype, int S, const double* K, const double* m, const double* sn2,
+                          int sn2_is_vector, gpc_post** post, double* sn2_mult, int* L_chol, int* info) {
+  int rc = check_batch_args(c, -1, 0, dtype, S);
+  if (rc) return rc;
+  if (!K || !m || !sn2 || !post || !sn2_mult || !L_chol || !info) FAIL(c, "gpc_posterior_batch_K: null argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  Batch b;
+  fill_batch(c, b, -1, 0, S, nullptr, m, sn2, sn2_is_vector);
+  gpc_post* po = new gpc_post();
+  po->ctx = c;
+  po->dtype = dtype;
+  po->S = S;
+  po->N = c->N;
+  po->D = c->D;
+  po->npad = c->npad;
+  po->cd = b.cd;
+  KArgs km{K, nullptr, nullptr};
+  rc = (dtype == GPC_F64) ? post_impl<double>(c, b, po, sn2_mult, L_chol, info, &km)
+                          : post_impl<float>(c, b, po, sn2_mult, L_chol, info, &km);
+  if (rc) {
+    c->pool_give(po->A);
+    c->pool_give(po->W);
+    c->pool_give(po->alpha);
+    delete po;
+    return rc;
+  }
+  *post = po;
+  return 0;
+}
+
+int gpc_predict_K(gpc_post* po, int M, const double* Ks, const double* Kss, double* fmu, double* fq, double* cov) {
+  if (!po) return -2;
+  gpc_ctx* c = po->ctx;
+  if (!Ks || !fmu || M <= 0 || (!fq && !cov) || (cov && !Kss)) FAIL(c, "gpc_predict_K: bad arguments");
+  for (int s = 0; s < po->S; ++s)
+    if (po->info[s] != 0) FAIL(c, "gpc_predict_K: posterior contains a failed factorization");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = po->dtype == GPC_F64 ? rhs_products<double>(po, 2, Ks, Kss, M, fq != nullptr, fmu, fq, cov)
+                                : rhs_products<float>(po, 2, Ks, Kss, M, fq != nullptr, fmu, fq, cov);
+  if (rc || !fq) return rc;
+  for (int s = 0; s < po->S; ++s) {  // the term the caller adds to kss (:1752-1764)
+    const double sl = po->sp[(size_t)s * SP_STRIDE + SP_SL];
+    for (int j = 0; j < M; ++j) {
+      double& q = fq[(size_t)j * po->S + s];
+      q = po->lchol[s] ? -q / sl : q;
+    }
+  }
+  return 0;
+}
+
 int gpc_post_fetch(gpc_post* po, int s, double* alpha, double* sW, double* L) {
   if (!po) return -2;
   gpc_ctx* c = po->ctx;
@@ -1722,6 +1892,7 @@ int gpc_post_append(gpc_post* po, const double* m_star, const double* sn2_star, 
   if (!po) return -2;
   gpc_ctx* c = po->ctx;
   if (!m_star || !sn2_star || !ok) FAIL(c, "gpc_post_append: null argument");
+  if (po->cd.kind < 0) FAIL(c, "gpc_post_append: not available for posteriors built from caller-provided K");
   HIPCHK(c, hipSetDevice(c->device));
   return po->dtype == GPC_F64 ? append_impl<double>(po, m_star, sn2_star, y_new, ok)
                               : append_impl<float>(po, m_star, sn2_star, y_new, ok);
@@ -1734,6 +1905,7 @@ int gpc_post_recompute(gpc_post* po, int cnt, const int* idx, const double* hyp_
   if (cnt <= 0 || !idx || !hyp_cov || !m || !sn2 || !sn2_mult || !L_chol || !info)
     FAIL(c, "gpc_post_recompute: bad arguments");
   if (c->N != po->N || c->D != po->D) FAIL(c, "gpc_post_recompute: the context's data do not match the posterior");
+  if (po->cd.kind < 0) FAIL(c, "gpc_post_recompute: not available for posteriors built from caller-provided K");
   for (int i = 0; i < cnt; ++i)
     if (idx[i] < 0 || idx[i] >= po->S) FAIL(c, "gpc_post_recompute: sample index out of range");
   HIPCHK(c, hipSetDevice(c->device));
@@ -1787,6 +1959,7 @@ int gpc_predict(gpc_post* po, const double* xstar, int M, double* fmu, double* f
   if (!po) return -2;
   gpc_ctx* c = po->ctx;
   if (!xstar || !fmu || !fs2 || M <= 0) FAIL(c, "gpc_predict: bad arguments");
+  if (po->cd.kind < 0) FAIL(c, "gpc_predict: this posterior was built from caller-provided K; use gpc_predict_K");
   for (int s = 0; s < po->S; ++s)
     if (po->info[s] != 0) FAIL(c, "gpc_predict: posterior contains a failed factorization");
   HIPCHK(c, hipSetDevice(c->device));
@@ -1798,6 +1971,7 @@ int gpc_predict_full(gpc_post* po, const double* xstar, int M, double* fmu, doub
   if (!po) return -2;
   gpc_ctx* c = po->ctx;
   if (!xstar || !fmu || !cov || M <= 0) FAIL(c, "gpc_predict_full: bad arguments");
+  if (po->cd.kind < 0) FAIL(c, "gpc_predict_full: this posterior was built from caller-provided K; use gpc_predict_K");
   for (int s = 0; s < po->S; ++s)
     if (po->info[s] != 0) FAIL(c, "gpc_predict_full: posterior contains a failed factorization");
   HIPCHK(c, hipSetDevice(c->device));

@@ -123,12 +123,12 @@ class GP:
         if dtype not in _DTYPES:
             raise ValueError("dtype must be 'f64' or 'f32'")
         self.dtype = dtype
-        if getattr(covariance, "_gpc_kernel_id", None) is None:
-            raise NotImplementedError(
-                "gpyreg_amd.GP runs the covariance on the device and supports the built-in "
-                "kernels (SquaredExponential, Matern, RationalQuadraticARD and the isotropic "
-                "variants); user-defined Python kernels are not on the accelerated path."
-            )
+        # Any object with the reference's covariance protocol is accepted (the reference calls
+        # whatever it was given: gaussian_process.py:2388-2390; AbstractKernel,
+        # covariance_functions.py:9-20).  The built-in kernels are evaluated on the device; any
+        # other object's own compute() supplies K and dK, and the factorization, solves and the
+        # gradient contraction still run on the device (gpc_nll_batch_K and friends).
+        self._builtin = getattr(covariance, "_gpc_kernel_id", None) is not None
         self.set_bounds()
         self.set_priors()
 
@@ -242,6 +242,19 @@ class GP:
     def _kid(self):
         return self.covariance._gpc_kernel_id, self.covariance._gpc_degree
 
+    def _user_cov(self, hyp_cov, grad):
+        """K (S,N,N) [and the per-sample dK (N,N,cov_N) arrays] from a user-defined covariance
+        object's own ``compute`` (the reference's call at gaussian_process.py:2388-2390)."""
+        Ks, dKs = [], []
+        for h in hyp_cov:
+            if grad:
+                K, dK = self.covariance.compute(h, self.X, compute_grad=True)
+                dKs.append(np.asarray(dK, dtype=float))
+            else:
+                K = self.covariance.compute(h, self.X)
+            Ks.append(np.asarray(K, dtype=float))
+        return np.stack(Ks), dKs
+
     # ------------------------------------------------------------------ core (batched)
     def nll_batch(self, hyp: np.ndarray, compute_grad: bool = False):
         """Negative log marginal likelihood (and gradient) for MANY hyperparameter
@@ -257,10 +270,16 @@ class GP:
             raise ValueError("Input hyperparameter array is the wrong shape!")
         ctx = self._ctx()
         pv = self._plugin_values(hyp, compute_grad)
-        kid, deg = self._kid()
-        nlz, dnlz, mult, lchol, info = ctx.nll_batch(
-            kid, deg, _DTYPES[self.dtype], hyp[:, :cov_N], pv["m"], pv["sn2"], pv["vec"],
-            compute_grad, pv["dm"], pv["dsn2"])
+        if self._builtin:
+            kid, deg = self._kid()
+            nlz, dnlz, mult, lchol, info = ctx.nll_batch(
+                kid, deg, _DTYPES[self.dtype], hyp[:, :cov_N], pv["m"], pv["sn2"], pv["vec"],
+                compute_grad, pv["dm"], pv["dsn2"])
+        else:
+            K, dK = self._user_cov(hyp[:, :cov_N], compute_grad)
+            nlz, dnlz, mult, lchol, info = ctx.nll_batch_K(
+                _DTYPES[self.dtype], K, (lambda s, p: dK[s][:, :, p]) if compute_grad else None, cov_N,
+                pv["m"], pv["sn2"], pv["vec"], compute_grad, pv["dm"], pv["dsn2"])
         if np.any(info != 0):
             raise LinAlgError("Singular matrix for L Cholesky decomposition")
         return nlz, dnlz
@@ -727,7 +746,7 @@ class GP:
         rank_one = (X_new is not None and y_new is not None and compute_posterior
                     and self.X is not None and self.y is not None and X_new.shape[0] == 1
                     and y_new.shape[0] == 1 and s2_new is None and hyp is None
-                    and self.s2 is None and self._post_handle is not None)
+                    and self.s2 is None and self._post_handle is not None and self._builtin)
         append_args = None
         if rank_one:
             cov_N, noise_N, mean_N = self._counts()
@@ -786,9 +805,14 @@ class GP:
         cov_N, _, _ = self._counts()
         ctx = self._ctx()
         pv = self._plugin_values(hyp, False)
-        kid, deg = self._kid()
-        handle, mult, lchol, info = ctx.posterior_batch(
-            kid, deg, _DTYPES[self.dtype], hyp[:, :cov_N], pv["m"], pv["sn2"], pv["vec"])
+        if self._builtin:
+            kid, deg = self._kid()
+            handle, mult, lchol, info = ctx.posterior_batch(
+                kid, deg, _DTYPES[self.dtype], hyp[:, :cov_N], pv["m"], pv["sn2"], pv["vec"])
+        else:
+            K, _ = self._user_cov(hyp[:, :cov_N], False)
+            handle, mult, lchol, info = ctx.posterior_batch_K(
+                _DTYPES[self.dtype], K, pv["m"], pv["sn2"], pv["vec"])
         if np.any(info != 0):
             handle.free()
             raise LinAlgError("Singular matrix for L Cholesky decomposition")
@@ -838,7 +862,14 @@ class GP:
             if self._post_handle is None:
                 raise ValueError("posteriors have been cleaned; call update() first")
             self._ctx()
-            fmu, fs2 = self._post_handle.predict(x_star)
+            if self._builtin:
+                fmu, fs2 = self._post_handle.predict(x_star)
+            else:  # user-defined kernel: its own cross covariances, the solves on the device
+                Ks = np.stack([self.covariance.compute(p.hyp[0:cov_N], self.X, x_star) for p in self.posteriors])
+                kss = np.stack([self.covariance.compute(p.hyp[0:cov_N], x_star, compute_diag=True)[:, 0]
+                                for p in self.posteriors], axis=1)
+                fmu, fq, _ = self._post_handle.predict_K(Ks)
+                fs2 = kss + fq
         y_s2 = np.zeros((N_star, s_N)) if (return_lpd or add_noise) else None
         lpd = np.zeros((N_star, s_N)) if (return_lpd and separate_samples) else None
 
@@ -895,7 +926,12 @@ class GP:
             if self._post_handle is None:
                 raise ValueError("posteriors have been cleaned; call update() first")
             self._ctx()
-            fmu, fcov = self._post_handle.predict_full(x_star)
+            if self._builtin:
+                fmu, fcov = self._post_handle.predict_full(x_star)
+            else:
+                Ks = np.stack([self.covariance.compute(p.hyp[0:cov_N], self.X, x_star) for p in self.posteriors])
+                Kss = np.stack([self.covariance.compute(p.hyp[0:cov_N], x_star) for p in self.posteriors])
+                fmu, _, fcov = self._post_handle.predict_K(Ks, Kss, want_var=False)
         for s in range(s_N):
             hyp = self.posteriors[s].hyp
             m_star = np.reshape(

@@ -81,6 +81,35 @@ int gpc_nll_batch(gpc_ctx* ctx, int kernel_id, int degree, int dtype, int S,
                   const double* dsn2, int noise_N, double* nlz, double* dnlz,
                   double* sn2_mult, int* L_chol, int* info);
 
+/* ---- the same for ANY covariance object: caller-provided K and dK -------------------------------
+ * The reference calls whatever object it was given -- `covariance.compute(hyp, X, compute_grad)`
+ * (gaussian_process.py:2388-2390; AbstractKernel, covariance_functions.py:9-20).  A kernel this
+ * library does not know is evaluated by the caller; the factorization, solves and the gradient
+ * contraction still run on the device:
+ *   K        S x N x N (row-major; symmetric)
+ *   dk_plane callback: fill plane[N*N] (row-major) with dK[:, :, p] of sample `sample`; called once
+ *            per (sample, p < cov_N) when want_grad, so the (N, N, cov_N) tensor is streamed one
+ *            plane at a time and never resident on the device.  Return 0, or nonzero to abort.
+ * Everything else (m, sn2, dm, dsn2, outputs, jitter escalation) as gpc_nll_batch; dnlz is ordered
+ * [cov (cov_N) | noise | mean].                                                                     */
+typedef int (*gpc_dk_plane_fn)(void* user, int sample, int p, double* plane);
+int gpc_nll_batch_K(gpc_ctx* ctx, int dtype, int S, int cov_N, const double* K, gpc_dk_plane_fn dk_plane,
+                    void* user, const double* m, const double* sn2, int sn2_is_vector, int want_grad,
+                    const double* dm, int mean_N, const double* dsn2, int noise_N, double* nlz,
+                    double* dnlz, double* sn2_mult, int* L_chol, int* info);
+/* Posteriors from caller-provided K (GP.update with a user-defined kernel).  Use gpc_predict_K with
+ * them; gpc_post_fetch / gpc_post_free as usual.                                                   */
+int gpc_posterior_batch_K(gpc_ctx* ctx, int dtype, int S, const double* K, const double* m,
+                          const double* sn2, int sn2_is_vector, gpc_post** post, double* sn2_mult,
+                          int* L_chol, int* info);
+/* Predictive products from caller-provided cross covariances Ks (S x N x M) -- works for posteriors
+ * of either origin:
+ *   fmu[j*S + s] = Ks_s[:, j] . alpha_s
+ *   fq [j*S + s] = -colsum(V*V) (L_chol) or +colsum(Ks * (L Ks)): ADD kss to get s2 (:1752-1764); may be NULL
+ *   cov[s]       = Kss_s - V^T V  or  Kss_s + Ks^T (L Ks)   (M x M; needs Kss, S x M x M); may be NULL  */
+int gpc_predict_K(gpc_post* post, int M, const double* Ks, const double* Kss, double* fmu, double* fq,
+                  double* cov);
+
 /* ---- GP.__core_computation(hyp, 0, 0) -> Posterior, for S vectors
  *      (gaussian_process.py:2514-2521; GP.update loop :870-884) ---------------------
  * The factors stay in HBM inside *post (freed by gpc_post_free).                   */

@@ -44,8 +44,12 @@ KERNELS = ("se", "matern", "rq", "se_iso", "matern_iso")
 MEANS = ("zero", "const", "negquad")
 
 
-def cov_count(kernel: str, D: int) -> int:
-    """covariance_functions.py:59-73, :291-292; isotropic_...py:14-28."""
+def cov_count(kernel, D: int) -> int:
+    """covariance_functions.py:59-73, :291-292; isotropic_...py:14-28.  ``kernel`` may also be an
+    object with the reference's covariance protocol (hyperparameter_count / compute): the
+    reference calls whatever object it was given (gaussian_process.py:2388-2390)."""
+    if hasattr(kernel, "hyperparameter_count"):
+        return kernel.hyperparameter_count(D)
     if kernel in ("se", "matern"):
         return D + 1
     if kernel == "rq":
@@ -103,6 +107,8 @@ def covariance(
     (scale X first, then SciPy distance, then the kernel function) because the
     golden test is bit-exact.
     """
+    if hasattr(kernel, "compute"):  # a covariance OBJECT: call it like the reference does
+        return kernel.compute(hyp, X, X_star, compute_diag=compute_diag, compute_grad=compute_grad)
     N, D = X.shape
     cov_N = cov_count(kernel, D)
     if hyp.size != cov_N:

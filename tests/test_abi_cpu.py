@@ -23,7 +23,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     lib = _lib.load()
     header = open(os.path.join(ROOT, "include", "gpcore.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
-    declared = set(re.findall(r"\b(gpc_[a-z0-9_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(gpc_[A-Za-z0-9_]+)\s*\(", header))
     assert declared, "no declarations parsed"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
