@@ -10,10 +10,12 @@ hyperparameter-derived vectors and D2H of (nlZ, dnlZ) are inside it.
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Multi-GPU: one process per GPU; samples are independent units, sharded with no
-data-path collective ("weak": every rank evaluates its own S samples); the only
-exchange is the RCCL all-gather of the per-sample [nlZ | dnlZ] vectors, done every
-step.  Rank 0 prints ONE JSON line.
+Multi-GPU: one process per GPU; samples are independent units.  Every rank passes the SAME
+global batch of world x S hyperparameter vectors to `GP.nll_batch`, which block-partitions
+them over the process group (gpyreg_amd/sharding.py: S per rank, "weak" scaling), evaluates its
+block on its own GPU and all-gathers the per-sample [nlZ | dnlZ] rows over RCCL -- the one
+exchange step of the path, done every step, inside the product's own API.  Rank 0 prints
+ONE JSON line.
 """
 
 import argparse
@@ -194,7 +196,7 @@ def main():
             dist.init_process_group("gloo")
     dev = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")
 
-    X, y, hyp = synthetic_problem(args.config, S, seed_shift=rank)
+    X, y, hyp = synthetic_problem(args.config, S * world)  # the global batch, identical on every rank
     gp = make_gp(args.config, dtype)
     gp.device = local_rank
     gp.update(X_new=X, y_new=y, hyp=hyp[:1], compute_posterior=False)  # X, y -> HBM on first use
@@ -206,14 +208,10 @@ def main():
     gathered = None
 
     def step():
+        # with a process group: sharded over the ranks and all-gathered inside GP.nll_batch
         nonlocal gathered
         nlz, dnlz = gp.nll_batch(hyp, compute_grad=grad)
-        if dist is not None:  # the one exchange step of the path: per-sample [nlZ | dnlZ]
-            loc = np.concatenate([nlz[:, None], dnlz if grad else np.zeros((S, 0))], axis=1)
-            t = torch.from_numpy(loc).to(dev)
-            out = torch.empty((world * t.shape[0], t.shape[1]), dtype=t.dtype, device=dev)
-            dist.all_gather_into_tensor(out, t)
-            gathered = out
+        gathered = nlz
         return nlz, dnlz
 
     def sync():
@@ -237,8 +235,7 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        if gathered is not None:  # every rank holds every sample's result
-            assert gathered.shape == (world * S, 1 + (hyp_N if grad else 0))
+        assert gathered.shape == (world * S,)  # every rank holds every sample's result
 
     # The dominant single kernel, timed alone: two extra UNTIMED steps with one sample group, so
     # the W^T W launch (gemm_persist_kernel<T,true,true,128,4>, all S samples in one grid) is not
@@ -247,8 +244,9 @@ def main():
     if rank == 0 and grad:
         groups_env = int(os.environ.get("GPC_GROUPS", "2"))
         ctx.set_option("groups", 1)
+        gp.shard = False  # rank-local extra steps (the other ranks are not in this loop)
         for _ in range(3):
-            gp.nll_batch(hyp, compute_grad=True)
+            gp.nll_batch(hyp[:S], compute_grad=True)
             lm, lau_fl = ctx.last_lauum_timing()
             lau_ms.append(lm)
         lau_ms = lau_ms[1:]

@@ -26,6 +26,7 @@ from numpy.linalg import LinAlgError  # scipy.linalg.LinAlgError is this class
 
 from . import _lib
 from . import priors as _pr
+from . import sharding as _sh
 from .f_min_fill import f_min_fill
 from .slice_sample import SliceSampler
 
@@ -123,6 +124,14 @@ class GP:
         if dtype not in _DTYPES:
             raise ValueError("dtype must be 'f64' or 'f32'")
         self.dtype = dtype
+        # Multi-GPU: when a torch.distributed process group with more than one rank is initialised
+        # (one process per GPU, torchrun), every batched entry point shards the hyperparameter samples
+        # over the ranks and all-gathers the per-sample results (the reference's loops over samples:
+        # f_min_fill.py:174-176, gaussian_process.py:876-879, :1727).  Every rank must call with the
+        # same arguments.  ``shard = False`` keeps this GP rank-local (replicas).
+        self.shard = True
+        self.process_group = None
+        self._post_range = None  # (lo, hi, S): the block of posterior samples resident on this rank
         # Any object with the reference's covariance protocol is accepted (the reference calls
         # whatever it was given: gaussian_process.py:2388-2390; AbstractKernel,
         # covariance_functions.py:9-20).  The built-in kernels are evaluated on the device; any
@@ -262,12 +271,35 @@ class GP:
 
         Equivalent to S calls of the reference's ``__core_computation(hyp, 1, grad)``
         (gaussian_process.py:2357-2512); raises ``LinAlgError`` if any sample is
-        still not positive definite after the 10 jitter escalations.
+        still not positive definite after the 10 jitter escalations.  Under an initialised
+        process group (and S > 1) the rows are sharded over the ranks and all-gathered: every
+        rank returns -- or raises -- the same thing.
         """
         hyp = np.atleast_2d(np.asarray(hyp, dtype=float))
         cov_N, noise_N, mean_N = self._counts()
-        if hyp.shape[1] != cov_N + noise_N + mean_N:
+        hyp_N = cov_N + noise_N + mean_N
+        if hyp.shape[1] != hyp_N:
             raise ValueError("Input hyperparameter array is the wrong shape!")
+        S = hyp.shape[0]
+        C = 1 + (hyp_N if compute_grad else 0)
+
+        def local(lo, hi):
+            nlz, dnlz, info = self._nll_batch_local(hyp[lo:hi], compute_grad)
+            rows = nlz[:, None] if not compute_grad else np.concatenate([nlz[:, None], dnlz], axis=1)
+            return rows, info != 0
+
+        if self.shard and S > 1 and _sh.active_group(self.process_group) is not None:
+            full, bad = _sh.gather_rows(S, C, local, self.process_group)
+        else:
+            full, bad = local(0, S)
+        if np.any(bad):
+            raise LinAlgError("Singular matrix for L Cholesky decomposition")
+        return full[:, 0].copy(), (full[:, 1:].copy() if compute_grad else None)
+
+    def _nll_batch_local(self, hyp, compute_grad):
+        """This rank's evaluation of the rows of ``hyp``: nlZ, dnlZ | None, info (no exception for a
+        failed sample: the caller decides, after the exchange when sharded)."""
+        cov_N, _, _ = self._counts()
         ctx = self._ctx()
         pv = self._plugin_values(hyp, compute_grad)
         if self._builtin:
@@ -280,9 +312,7 @@ class GP:
             nlz, dnlz, mult, lchol, info = ctx.nll_batch_K(
                 _DTYPES[self.dtype], K, (lambda s, p: dK[s][:, :, p]) if compute_grad else None, cov_N,
                 pv["m"], pv["sn2"], pv["vec"], compute_grad, pv["dm"], pv["dsn2"])
-        if np.any(info != 0):
-            raise LinAlgError("Singular matrix for L Cholesky decomposition")
-        return nlz, dnlz
+        return nlz, dnlz, info
 
     def __compute_nlZ(self, hyp, compute_grad, compute_prior):
         """Reference gaussian_process.py:1520-1538 (single hyperparameter vector)."""
@@ -746,12 +776,14 @@ class GP:
         rank_one = (X_new is not None and y_new is not None and compute_posterior
                     and self.X is not None and self.y is not None and X_new.shape[0] == 1
                     and y_new.shape[0] == 1 and s2_new is None and hyp is None
-                    and self.s2 is None and self._post_handle is not None and self._builtin)
+                    and self.s2 is None and self._post_handle is not None and self._builtin
+                    and self._post_range is None)  # sharded posteriors: recompute (every rank in step)
         append_args = None
         if rank_one:
             cov_N, noise_N, mean_N = self._counts()
             m_star, sn2_star = [], []
-            for p in self.posteriors:
+            local_posts, first = self._local_posteriors()
+            for p in local_posts:
                 h = p.hyp
                 sn2 = self.noise.compute(h[cov_N:cov_N + noise_N], X_new, y_new, 0)
                 if not np.isscalar(sn2):
@@ -775,15 +807,15 @@ class GP:
             redo = np.flatnonzero(~ok)
             if redo.size:  # unstable for these posteriors only: full update of exactly those (:789-798, :866-869)
                 cov_N, _, _ = self._counts()
-                hyp_r = np.stack([self.posteriors[i].hyp for i in redo])
+                hyp_r = np.stack([local_posts[i].hyp for i in redo])
                 pv = self._plugin_values(hyp_r, False)
                 mult, lchol, info = self._post_handle.recompute(redo, hyp_r[:, :cov_N], pv["m"], pv["sn2"], pv["vec"])
                 if np.any(info != 0):
                     raise LinAlgError("Singular matrix for L Cholesky decomposition")
                 for k, i in enumerate(redo):
                     m = mult[k]
-                    self.posteriors[i].sn2_mult = int(m) if m < 2**62 else m
-                    self.posteriors[i].L_chol = bool(lchol[k])
+                    local_posts[i].sn2_mult = int(m) if m < 2**62 else m
+                    local_posts[i].L_chol = bool(lchol[k])
             for p in self.posteriors:  # cached host copies are stale; refetch lazily
                 p._alpha = p._sW = p._L = None
                 p._have = {"alpha": False, "sW": False, "L": False}
@@ -801,27 +833,68 @@ class GP:
                 self.posteriors[i] = Posterior(hyp[i, :], None, None, None, None, None)
 
     def _compute_posteriors(self, hyp):
-        """S x ``__core_computation(hyp, 0, 0)`` (reference :876-879) in one batch."""
+        """S x ``__core_computation(hyp, 0, 0)`` (reference :876-879) in one batch.  Under a process
+        group the samples are block-partitioned: this rank factors and keeps ONLY its block
+        (``_post_range``); ``sn2_mult`` / ``L_chol`` of every sample are exchanged, the factors never are.
+        ``Posterior.alpha/.sW/.L`` of a sample that lives on another rank read as ``None``."""
         cov_N, _, _ = self._counts()
-        ctx = self._ctx()
-        pv = self._plugin_values(hyp, False)
-        if self._builtin:
-            kid, deg = self._kid()
-            handle, mult, lchol, info = ctx.posterior_batch(
-                kid, deg, _DTYPES[self.dtype], hyp[:, :cov_N], pv["m"], pv["sn2"], pv["vec"])
-        else:
-            K, _ = self._user_cov(hyp[:, :cov_N], False)
-            handle, mult, lchol, info = ctx.posterior_batch_K(
-                _DTYPES[self.dtype], K, pv["m"], pv["sn2"], pv["vec"])
-        if np.any(info != 0):
-            handle.free()
+        S = hyp.shape[0]
+        made = {}
+
+        def local(lo, hi):
+            ctx = self._ctx()
+            pv = self._plugin_values(hyp[lo:hi], False)
+            if self._builtin:
+                kid, deg = self._kid()
+                handle, mult, lchol, info = ctx.posterior_batch(
+                    kid, deg, _DTYPES[self.dtype], hyp[lo:hi, :cov_N], pv["m"], pv["sn2"], pv["vec"])
+            else:
+                K, _ = self._user_cov(hyp[lo:hi, :cov_N], False)
+                handle, mult, lchol, info = ctx.posterior_batch_K(
+                    _DTYPES[self.dtype], K, pv["m"], pv["sn2"], pv["vec"])
+            made["handle"], made["lo"], made["hi"] = handle, lo, hi
+            return np.stack([mult, lchol.astype(float)], axis=1), info != 0
+
+        sharded = self.shard and S > 1 and _sh.active_group(self.process_group) is not None
+        try:
+            if sharded:
+                full, bad = _sh.gather_rows(S, 2, local, self.process_group)
+            else:
+                full, bad = local(0, S)
+        except Exception:
+            if "handle" in made:
+                made["handle"].free()
+            raise
+        if np.any(bad):
+            if "handle" in made:
+                made["handle"].free()
             raise LinAlgError("Singular matrix for L Cholesky decomposition")
+        handle = made.get("handle")
+        lo, hi = made.get("lo", 0), made.get("hi", 0)
         self._post_handle = handle
-        for i in range(hyp.shape[0]):
-            m = mult[i]
+        self._post_range = (lo, hi, S) if sharded else None
+        for i in range(S):
+            m = full[i, 0]
+            mine = handle is not None and lo <= i < hi
             self.posteriors[i] = Posterior(
-                hyp[i, :], None, None, None, int(m) if m < 2**62 else m, bool(lchol[i]),
-                _handle=handle, _index=i)
+                hyp[i, :], None, None, None, int(m) if m < 2**62 else m, bool(full[i, 1]),
+                _handle=handle if mine else None, _index=(i - lo) if mine else None)
+
+    def _local_posteriors(self):
+        """The posterior records whose factors are resident on this rank (all of them unless sharded)."""
+        if self._post_range is None:
+            return list(self.posteriors), 0
+        lo, hi, _ = self._post_range
+        return list(self.posteriors[lo:hi]), lo
+
+    def _gather_samples(self, local_cols):
+        """(R, S_local) per-sample columns of this rank -> (R, S) on every rank (no-op unless sharded)."""
+        if self._post_range is None:
+            return local_cols
+        lo, hi, S = self._post_range
+        R = local_cols.shape[0]
+        full, _ = _sh.gather_rows(S, R, lambda a, b: (local_cols.T, np.zeros(b - a, bool)), self.process_group)
+        return full.T.copy()
 
     def _drop_handle(self):
         if self._post_handle is not None:
@@ -831,6 +904,7 @@ class GP:
                         p._detach()
             self._post_handle.free()
             self._post_handle = None
+        self._post_range = None
 
     def clean(self):
         """Drop the auxiliary structures (reference :886-905); ``update`` rebuilds them."""
@@ -859,17 +933,23 @@ class GP:
         mu = np.zeros((N_star, s_N))
         s2 = np.zeros((N_star, s_N))
         if self.y is not None:
-            if self._post_handle is None:
+            if self._post_handle is None and self._post_range is None:
                 raise ValueError("posteriors have been cleaned; call update() first")
             self._ctx()
-            if self._builtin:
+            local_posts, _ = self._local_posteriors()
+            if not local_posts:
+                fmu = fs2 = np.zeros((N_star, 0))
+            elif self._builtin:
                 fmu, fs2 = self._post_handle.predict(x_star)
             else:  # user-defined kernel: its own cross covariances, the solves on the device
-                Ks = np.stack([self.covariance.compute(p.hyp[0:cov_N], self.X, x_star) for p in self.posteriors])
+                Ks = np.stack([self.covariance.compute(p.hyp[0:cov_N], self.X, x_star) for p in local_posts])
                 kss = np.stack([self.covariance.compute(p.hyp[0:cov_N], x_star, compute_diag=True)[:, 0]
-                                for p in self.posteriors], axis=1)
+                                for p in local_posts], axis=1)
                 fmu, fq, _ = self._post_handle.predict_K(Ks)
                 fs2 = kss + fq
+            if self._post_range is not None:  # each rank predicted its block of samples: one all-gather
+                both = self._gather_samples(np.concatenate([fmu, fs2], axis=0))
+                fmu, fs2 = both[:N_star], both[N_star:]
         y_s2 = np.zeros((N_star, s_N)) if (return_lpd or add_noise) else None
         lpd = np.zeros((N_star, s_N)) if (return_lpd and separate_samples) else None
 
@@ -923,15 +1003,21 @@ class GP:
         mu = np.zeros((N_star, s_N))
         cov = np.zeros((s_N, N_star, N_star))
         if self.y is not None:
-            if self._post_handle is None:
+            if self._post_handle is None and self._post_range is None:
                 raise ValueError("posteriors have been cleaned; call update() first")
             self._ctx()
-            if self._builtin:
+            local_posts, _ = self._local_posteriors()
+            if not local_posts:
+                fmu, fcov = np.zeros((N_star, 0)), np.zeros((0, N_star, N_star))
+            elif self._builtin:
                 fmu, fcov = self._post_handle.predict_full(x_star)
             else:
-                Ks = np.stack([self.covariance.compute(p.hyp[0:cov_N], self.X, x_star) for p in self.posteriors])
-                Kss = np.stack([self.covariance.compute(p.hyp[0:cov_N], x_star) for p in self.posteriors])
+                Ks = np.stack([self.covariance.compute(p.hyp[0:cov_N], self.X, x_star) for p in local_posts])
+                Kss = np.stack([self.covariance.compute(p.hyp[0:cov_N], x_star) for p in local_posts])
                 fmu, _, fcov = self._post_handle.predict_K(Ks, Kss, want_var=False)
+            if self._post_range is not None:
+                both = self._gather_samples(np.concatenate([fmu, fcov.reshape(fcov.shape[0], -1).T], axis=0))
+                fmu, fcov = both[:N_star], both[N_star:].T.reshape(-1, N_star, N_star)
         for s in range(s_N):
             hyp = self.posteriors[s].hyp
             m_star = np.reshape(
@@ -968,10 +1054,16 @@ class GP:
         N_star = mu.shape[0]
         sigma = np.tile(sigma, (1, D)) if np.size(sigma) == 1 else np.atleast_2d(np.asarray(sigma, dtype=float))
         sigma = np.broadcast_to(sigma, mu.shape).astype(float)
-        if self._post_handle is None:
+        if self._post_handle is None and self._post_range is None:
             raise ValueError("posteriors have been cleaned; call update() first")
         self._ctx()
-        za, zkz = self._post_handle.quad(mu, sigma, compute_var)
+        if self._post_handle is not None:
+            za, zkz = self._post_handle.quad(mu, sigma, compute_var)
+        else:
+            za, zkz = np.zeros((N_star, 0)), (np.zeros((N_star, 0)) if compute_var else None)
+        if self._post_range is not None:
+            both = self._gather_samples(np.concatenate([za, zkz], axis=0) if compute_var else za)
+            za, zkz = both[:N_star], (both[N_star:] if compute_var else None)
         quadratic = isinstance(self.mean, NegativeQuadratic)
         F = np.zeros((N_star, N_s))
         F_var = np.zeros((N_star, N_s)) if compute_var else None

@@ -55,6 +55,61 @@ def _all_gather_rows(local: np.ndarray, S: int, group=None) -> np.ndarray:
     return np.concatenate(rows, axis=0)
 
 
+def active_group(group=None):
+    """``(rank, world)`` when a torch.distributed process group with more than one rank is
+    initialised (torch is only touched if the caller imported it already), else None."""
+    import sys
+
+    if "torch" not in sys.modules:
+        return None
+    dist = _dist()
+    if dist is None or dist.get_world_size(group) == 1:
+        return None
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+class ShardError(RuntimeError):
+    """A rank failed inside a sharded evaluation (raised on EVERY rank after the exchange)."""
+
+
+def gather_rows(S: int, ncols: int, compute_local, group=None):
+    """Run ``compute_local(lo, hi) -> (rows (hi-lo, ncols), bad (hi-lo,) bool)`` on this rank's block
+    and return the full ``(S, ncols)`` array and the full ``bad`` mask on every rank.
+
+    A rank whose block raises does NOT leave the others waiting in the collective: the exception is
+    caught, the rank still enters the all-gather with a status column, and every rank raises
+    ``ShardError`` afterwards (a non-positive-definite sample on one shard is an expected event
+    during fitting; it must not become a hang)."""
+    rw = active_group(group)
+    if rw is None:
+        rows, bad = compute_local(0, S)
+        return np.asarray(rows, dtype=float).reshape(S, ncols), np.asarray(bad, dtype=bool)
+    rank, world = rw
+    lo, hi = shard_bounds(S, rank, world)
+    local = np.zeros((hi - lo, ncols + 1))
+    err = None
+    try:
+        if hi > lo:
+            rows, bad = compute_local(lo, hi)
+            local[:, :ncols] = np.asarray(rows, dtype=float).reshape(hi - lo, ncols)
+            local[:, ncols] = np.asarray(bad, dtype=float)
+    except Exception as e:  # noqa: BLE001 - exchanged, then raised on every rank
+        err = e
+        local[:, :ncols] = 0.0
+        local[:, ncols] = 2.0
+    # a rank with an empty block that failed still has to be heard: one extra status row per rank
+    flag = np.zeros((1, ncols + 1))
+    flag[0, ncols] = 2.0 if err is not None else 0.0
+    full = _all_gather_rows(local, S, group)
+    flags = _all_gather_rows(flag, world, group)
+    if err is not None:
+        raise ShardError(f"rank {rank}: {type(err).__name__}: {err}") from err
+    if np.any(flags[:, ncols] == 2.0) or np.any(full[:, ncols] == 2.0):
+        failed = [r for r in range(world) if flags[r, ncols] == 2.0]
+        raise ShardError(f"sharded evaluation failed on rank(s) {failed}")
+    return full[:, :ncols].copy(), full[:, ncols] != 0.0
+
+
 def nll_batch_sharded(gp, hyp: np.ndarray, compute_grad: bool = False, group=None):
     """``gp.nll_batch`` with the samples sharded over the process group.
 
@@ -64,8 +119,8 @@ def nll_batch_sharded(gp, hyp: np.ndarray, compute_grad: bool = False, group=Non
     hyp = np.atleast_2d(np.asarray(hyp, dtype=float))
     S, hyp_N = hyp.shape
     dist = _dist()
-    if dist is None or dist.get_world_size(group) == 1:
-        return gp.nll_batch(hyp, compute_grad)
+    if dist is None or dist.get_world_size(group) == 1 or getattr(gp, "shard", False):
+        return gp.nll_batch(hyp, compute_grad)  # a gpyreg_amd.GP shards by itself
     lo, hi = shard_bounds(S, dist.get_rank(group), dist.get_world_size(group))
     C = 1 + (hyp_N if compute_grad else 0)
     local = np.zeros((hi - lo, C))
@@ -85,7 +140,7 @@ def predict_sharded(gp, x_star: np.ndarray, group=None):
     gaussian_process.py:1663-1787; sample averaging is then rank-local arithmetic)."""
     mu, s2 = gp.predict(x_star, separate_samples=True)
     dist = _dist()
-    if dist is None or dist.get_world_size(group) == 1:
+    if dist is None or dist.get_world_size(group) == 1 or getattr(gp, "shard", False):
         return mu, s2
     import torch
 

@@ -1,0 +1,115 @@
+"""The multi-GPU path with the REAL GP on a device: two fresh processes (torch.distributed, gloo
+rendezvous, both on GPU 0) run gpyreg_amd.GP under an initialised process group; every batched
+entry point shards the hyperparameter samples over the ranks and all-gathers the per-sample
+results (reference loops: f_min_fill.py:174-176, gaussian_process.py:876-879, :1727).  Sharded
+results must equal the unsharded ones bit for bit, for S = 5 (blocks of 3 and 2) and S = 16."""
+
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      GPYREG_AMD_DEVICE="0")
+    import torch.distributed as dist
+    from numpy.linalg import LinAlgError
+
+    import bench
+    from gpyreg_amd import sharding
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = {}
+    try:
+        bench.CONFIGS[3] = dict(bench.CONFIGS[3], N=700)
+        for S in (5, 16):
+            X, y, hyp = bench.synthetic_problem(3, S)
+            xs = X[:40] + 0.05
+            ref = bench.make_gp(3, "f64")
+            ref.shard = False  # rank-local: the unsharded answer
+            ref.update(X_new=X, y_new=y, hyp=hyp)
+            rn, rd = ref.nll_batch(hyp, compute_grad=True)
+            rn0, _ = ref.nll_batch(hyp, compute_grad=False)
+            rmu, rs2 = ref.predict(xs, separate_samples=True)
+            ramu, ras2 = ref.predict(xs, add_noise=True)
+            rfm, rfc = ref.predict_full(xs[:7])
+            gp = bench.make_gp(3, "f64")  # shard = True by default
+            gp.update(X_new=X, y_new=y, hyp=hyp)
+            lo, hi = sharding.shard_bounds(S, rank, world)
+            assert gp._post_range == (lo, hi, S) and gp._post_handle.S == hi - lo
+            n, d = gp.nll_batch(hyp, compute_grad=True)
+            n0, _ = gp.nll_batch(hyp, compute_grad=False)
+            mu, s2 = gp.predict(xs, separate_samples=True)
+            amu, as2 = gp.predict(xs, add_noise=True)
+            fm, fc = gp.predict_full(xs[:7])
+            out[S] = dict(
+                nll=bool(np.array_equal(n, rn) and np.array_equal(d, rd)),
+                nll_only=bool(np.array_equal(n0, rn0)),
+                pred=bool(np.array_equal(mu, rmu) and np.array_equal(s2, rs2)),
+                avg=bool(np.array_equal(amu, ramu) and np.array_equal(as2, ras2)),
+                full=bool(np.array_equal(fm, rfm) and np.array_equal(fc, rfc)),
+                flags=bool(all(a.sn2_mult == b.sn2_mult and a.L_chol == b.L_chol
+                               for a, b in zip(gp.posteriors, ref.posteriors))),
+                local_alpha=bool(all((gp.posteriors[i].alpha is not None) == (lo <= i < hi) for i in range(S))),
+                alpha_eq=bool(all(np.array_equal(gp.posteriors[i].alpha, ref.posteriors[i].alpha) for i in range(lo, hi))),
+            )
+        # one shard holds a sample that stays non-PD after 10 escalations: EVERY rank raises, nobody hangs
+        X, y, hyp = bench.synthetic_problem(3, 4)
+        gp = bench.make_gp(3, "f64")
+        gp.update(X_new=X, y_new=y, hyp=hyp[:1], compute_posterior=False)
+        bad = hyp.copy()
+        bad[3, 10] = 400.0  # log sigma_f = 400 -> K overflows to inf on rank 1's block only
+        try:
+            gp.nll_batch(bad, compute_grad=True)
+            out["err"] = "no exception"
+        except LinAlgError:
+            out["err"] = "LinAlgError"
+        except sharding.ShardError as e:
+            out["err"] = "ShardError"
+        # and the group is still usable afterwards
+        n2, _ = gp.nll_batch(hyp, compute_grad=False)
+        out["after"] = bool(np.isfinite(n2).all())
+        q.put((rank, out))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+
+        q.put((rank, {"exception": traceback.format_exc()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_gp_equals_unsharded_bitwise_two_ranks_one_gpu():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        r = res[rank]
+        assert "exception" not in r, r.get("exception")
+        for S in (5, 16):
+            assert all(r[S].values()), (rank, S, sorted(k for k, v in r[S].items() if not v))
+        assert r["err"] in ("LinAlgError", "ShardError"), r["err"]
+        assert r["after"]

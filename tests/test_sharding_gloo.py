@@ -112,3 +112,54 @@ def test_single_process_passthrough():
     gp = _OracleGP(model, X, y)
     nlz, dnlz = sharding.nll_batch_sharded(gp, hyp, compute_grad=True)
     assert gp.calls == [3] and nlz.shape == (3,) and dnlz.shape == (3, 5)
+
+
+def _err_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    from gpyreg_amd import sharding
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        res = []
+        # (1) rank 1's block raises: both ranks must come back with ShardError (no hang in the collective)
+        def boom(lo, hi):
+            if rank == 1:
+                raise FloatingPointError("singular block")
+            return np.ones((hi - lo, 3)), np.zeros(hi - lo, bool)
+        try:
+            sharding.gather_rows(5, 3, boom)
+            res.append("no error")
+        except sharding.ShardError as e:
+            res.append("ShardError")
+        # (2) a per-sample failure flag (not an exception) reaches every rank
+        rows, bad = sharding.gather_rows(
+            5, 2, lambda lo, hi: (np.arange(lo, hi)[:, None] * np.ones((1, 2)), np.arange(lo, hi) == 4))
+        res.append((rows[:, 0].tolist(), bad.tolist()))
+        # (3) more ranks than samples: rank 1 has an empty block and still takes part
+        rows, bad = sharding.gather_rows(1, 1, lambda lo, hi: (np.full((hi - lo, 1), 7.0), np.zeros(hi - lo, bool)))
+        res.append(rows.ravel().tolist())
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_failing_shard_raises_on_every_rank_instead_of_hanging():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_err_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        assert res[rank][0] == "ShardError"
+        assert res[rank][1] == ([0.0, 1.0, 2.0, 3.0, 4.0], [False, False, False, False, True])
+        assert res[rank][2] == [7.0]
