@@ -329,6 +329,30 @@ def fit_cases():
         out[tag + "_xs"], out[tag + "_mu"], out[tag + "_s2"] = xs, mu, s2
         out[tag + "_lb"], out[tag + "_ub"] = gp.lower_bounds, gp.upper_bounds
         print(tag, kname, "opt fun", opt_res.fun, "hyp[0]", hyp[0])
+    # f2: the reference's own examples/example_1.py -- same seed, data, model, prior and options
+    # (Matern-3 + NegativeQuadratic + constant and user-provided noise, Student-t prior, N=31, D=1)
+    from scipy.stats import norm
+
+    np.random.seed(1234)
+    N, D = 31, 1
+    X = -5 + np.random.rand(N, 1) * 10
+    s2 = 0.05 * np.exp(0.5 * X)
+    y = np.sin(X) + np.sqrt(s2) * norm.ppf(np.random.random_sample(X.shape))
+    y[y < 0] = -np.abs(3 * y[y < 0]) ** 2
+    gp = gpr.GP(D=D, covariance=gpr.covariance_functions.Matern(degree=3),
+                mean=gpr.mean_functions.NegativeQuadratic(),
+                noise=gpr.noise_functions.GaussianNoise(constant_add=True, user_provided_add=True))
+    gp.set_priors({"covariance_log_lengthscale": None, "covariance_log_outputscale": None, "mean_const": None,
+                   "mean_location": None, "mean_log_scale": None,
+                   "noise_log_scale": ("student_t", (np.log(1e-3), 1.0, 7))})
+    hyp, opt_res, samp = gp.fit(X=X, y=y, s2=s2, options={"n_samples": 10})
+    x_star = np.reshape(np.linspace(-15, 15, 200), (-1, 1))
+    fmu, fs2 = gp.predict(x_star, add_noise=False)
+    out["f2_X"], out["f2_y"], out["f2_s2"], out["f2_hyp"] = X, y, s2, hyp
+    out["f2_opt_x"], out["f2_opt_fun"] = opt_res.x, np.array(opt_res.fun)
+    out["f2_mu"], out["f2_fs2"] = fmu, fs2
+    out["f2_lb"], out["f2_ub"] = gp.lower_bounds, gp.upper_bounds
+    print("f2 example_1 opt fun", opt_res.fun, "hyp[0]", hyp[0])
     np.savez_compressed(os.path.join(HERE, "fit_cases.npz"), **out)
 
 

@@ -50,6 +50,41 @@ def test_fit_reproduces_reference_run(idx):
     assert gp.posteriors.size == 6 and gp.get_hyperparameters(as_array=True).shape == hyp.shape
 
 
+def test_fit_reproduces_the_reference_example_1():
+    """BASELINE config 1 / the reference's own examples/example_1.py: Matern-3 + NegativeQuadratic +
+    GaussianNoise(constant_add, user_provided_add) + a Student-t prior on the noise, N = 31, D = 1,
+    default fit options (1024-point design, 3 starts, 10 slice samples) -- against the reference's
+    seeded run (tests/golden/fit_cases.npz, f2_*)."""
+    from scipy.stats import norm
+
+    import gpyreg_amd as gpr
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fit_cases.npz"), allow_pickle=False)
+    np.random.seed(1234)
+    N, D = 31, 1
+    X = -5 + np.random.rand(N, 1) * 10
+    s2 = 0.05 * np.exp(0.5 * X)
+    y = np.sin(X) + np.sqrt(s2) * norm.ppf(np.random.random_sample(X.shape))
+    y[y < 0] = -np.abs(3 * y[y < 0]) ** 2
+    assert np.array_equal(X, g["f2_X"]) and np.array_equal(y, g["f2_y"]) and np.array_equal(s2, g["f2_s2"])
+    gp = gpr.GP(D=D, covariance=gpr.covariance_functions.Matern(degree=3),
+                mean=gpr.mean_functions.NegativeQuadratic(),
+                noise=gpr.noise_functions.GaussianNoise(constant_add=True, user_provided_add=True))
+    gp.set_priors({"covariance_log_lengthscale": None, "covariance_log_outputscale": None, "mean_const": None,
+                   "mean_location": None, "mean_log_scale": None,
+                   "noise_log_scale": ("student_t", (np.log(1e-3), 1.0, 7))})
+    hyp, opt_res, samp = gp.fit(X=X, y=y, s2=s2, options={"n_samples": 10})
+    assert np.allclose(gp.lower_bounds, g["f2_lb"]) and np.allclose(gp.upper_bounds, g["f2_ub"])
+    assert abs(opt_res.fun - g["f2_opt_fun"]) < 1e-6 * max(1.0, abs(g["f2_opt_fun"]))
+    assert np.allclose(opt_res.x, g["f2_opt_x"], atol=1e-4)
+    assert hyp.shape == g["f2_hyp"].shape == (10, 6)
+    assert np.allclose(hyp, g["f2_hyp"], atol=5e-3), np.abs(hyp - g["f2_hyp"]).max()
+    x_star = np.reshape(np.linspace(-15, 15, 200), (-1, 1))
+    fmu, fs2 = gp.predict(x_star, add_noise=False)
+    scale = np.abs(g["f2_mu"]).max()
+    assert np.abs(fmu - g["f2_mu"]).max() <= 2e-2 * scale and np.abs(fs2 - g["f2_fs2"]).max() <= 2e-2 * np.abs(g["f2_fs2"]).max()
+
+
 def test_fit_recovers_generating_hyperparameters():
     """reference test_gaussian_process.py:809-849: fit recovers the generating
     hyperparameters (here on the device, N = 500, Matern-5)."""
