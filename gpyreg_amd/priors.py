@@ -170,8 +170,11 @@ def log_priors(hyp, hp, lb, ub, norm_const, compute_grad=False):
             C = 1.0 + (b[sel] - a[sel]) * _t_norm(df[sel], sigma[sel])
         else:
             C = 1.0 + (b[sel] - a[sel]) / (sigma[sel] * _S2PI)
-        Cfull = np.ones(hyp.shape)
-        Cfull[sel] = C
+        # NOTE: C is the vector over ALL dimensions of this class and is broadcast, as in the reference
+        # (:1346-1356, :1391-1413), against the subset of those dimensions that lies outside / inside
+        # [a, b].  With several smooth-box dimensions in different regions that either counts terms
+        # several times (subset of size 1) or raises numpy's broadcasting ValueError -- the reference's
+        # arithmetic, reproduced here so that a seeded fit is identical.
         below = (hyp < a) & sel
         above = (hyp > b) & sel
         inside = (hyp >= a) & (hyp <= b) & sel
@@ -184,19 +187,20 @@ def log_priors(hyp, hp, lb, ub, norm_const, compute_grad=False):
                 if np.any(grp):
                     lp += np.sum(sps.gammaln(0.5 * (df[grp] + 1)) - sps.gammaln(0.5 * df[grp]))
                     tail = -0.5 * (df[grp] + 1) * np.log1p(zz[grp] / df[grp]) if grp is out else 0.0
-                    lp += np.sum(-0.5 * np.log(np.pi * df[grp]) - np.log(Cfull[grp] * sigma[grp]) + tail)
+                    lp += np.sum(-0.5 * np.log(np.pi * df[grp]) - np.log(C * sigma[grp]) + tail)
         else:
             if np.any(out):
-                lp -= 0.5 * np.sum(np.log(Cfull[out] ** 2 * 2 * np.pi * sigma[out] ** 2) + zz[out])
+                lp -= 0.5 * np.sum(np.log(C**2 * 2 * np.pi * sigma[out] ** 2) + zz[out])
             if np.any(inside):
-                lp -= np.sum(np.log(Cfull[inside] * sigma[inside]) + np.log(_S2PI))
+                lp -= np.sum(np.log(C * sigma[inside]) + np.log(_S2PI))
         if compute_grad:
             for grp, edge in ((below, a), (above, b)):
                 if np.any(grp):
-                    g = -(hyp[grp] - edge[grp]) / sigma[grp] ** 2
-                    if student:
-                        g = g * (df[grp] + 1) / df[grp] / (1 + zz[grp] / df[grp])
-                    dlp[grp] = g
+                    if student:  # same operation order as the reference: results are compared bit for bit
+                        dlp[grp] = (-(df[grp] + 1) / df[grp] / (1 + zz[grp] / df[grp]) * (hyp[grp] - edge[grp])
+                                    / sigma[grp] ** 2)
+                    else:
+                        dlp[grp] = -(hyp[grp] - edge[grp]) / sigma[grp] ** 2
 
     box_part(ix["sb"], False)
     box_part(ix["sb_t"], True)

@@ -299,6 +299,40 @@ def prior_cases():
         out[tag + "_dLB"], out[tag + "_dUB"], out[tag + "_dPLB"], out[tag + "_dPUB"] = LB, UB, PLB, PUB
         out[tag + "_dx0"], out[tag + "_dX"], out[tag + "_dy"] = x0, Xd, yd
         names.append(f"{tag}|{hyp_N}")
+    # smooth-box priors on SEVERAL dimensions in different regions: the reference broadcasts the
+    # per-class normaliser against the subset outside [a, b] (:1346-1356): one dimension outside ->
+    # its term is counted once per class member; two of three outside -> numpy's broadcasting error
+    for kind, tag, Dq in (("smoothbox", "q0", 3), ("smoothbox_student_t", "q1", 3), ("smoothbox", "q2", 2),
+                          ("smoothbox_student_t", "q3", 2)):
+        gp = gpr.GP(D=Dq, covariance=KERNELS["se"](), mean=MEANS["const"](), noise=make_noise((1, 0, 0)))
+        par = (np.array([-1.0, -1.5, -0.5])[:Dq], np.array([1.0, 0.5, 1.5])[:Dq], np.array([0.7, 0.9, 1.1])[:Dq])
+        pri = {name: None for name, _ in (gp.covariance.hyperparameter_info(Dq) + gp.noise.hyperparameter_info()
+                                          + gp.mean.hyperparameter_info(Dq))}
+        pri["covariance_log_lengthscale"] = (kind, par if kind == "smoothbox" else par + (np.array([3.0, 4.0, 5.0])[:Dq],))
+        gp.set_priors(pri)
+        gp.hyper_priors["df"][np.isnan(gp.hyper_priors["df"])] = 7
+        gp._GP__recompute_normalization_constants()
+        if Dq == 3:
+            H = np.array([[0.0, 0.0, 0.0, 0.1, 0.2, 0.3],     # all inside
+                          [2.0, 0.0, 0.0, 0.1, 0.2, 0.3],     # one above, two inside: broadcasting error
+                          [-3.0, -3.0, 2.5, 0.1, 0.2, 0.3],   # all outside
+                          [2.0, -3.0, 0.0, 0.1, 0.2, 0.3]])   # two outside, one inside: broadcasting error
+        else:
+            H = np.array([[0.0, 0.0, 0.1, 0.2, 0.3],          # both inside
+                          [2.0, 0.0, 0.1, 0.2, 0.3],          # one above, one inside: terms counted twice
+                          [-3.0, 2.5, 0.1, 0.2, 0.3],         # both outside
+                          [0.5, -4.0, 0.1, 0.2, 0.3]])        # one inside, one below: terms counted twice
+        lp, dlp, raised = np.full(4, np.nan), np.full((4, H.shape[1]), np.nan), np.zeros(4, bool)
+        for r in range(4):
+            try:
+                lp[r], dlp[r] = gp._GP__compute_log_priors(H[r], True)
+            except ValueError:
+                raised[r] = True
+        for k in ("mu", "sigma", "df", "a", "b"):
+            out[tag + "_" + k] = gp.hyper_priors[k]
+        out[tag + "_lb"], out[tag + "_ub"], out[tag + "_norm"] = gp.lower_bounds, gp.upper_bounds, gp.normalization_constants
+        out[tag + "_H"], out[tag + "_lp"], out[tag + "_dlp"], out[tag + "_raised"] = H, lp, dlp, raised
+        print(tag, kind, "lp", lp, "raised", raised)
     out["names"] = np.array(names)
     np.savez_compressed(os.path.join(HERE, "prior_cases.npz"), **out)
     print("prior cases:", len(names))

@@ -58,6 +58,29 @@ def test_log_priors_and_normalization_match_reference(g):
     assert compared >= 40
 
 
+def test_multi_dimensional_smoothbox_reproduces_the_reference_arithmetic(g):
+    """Smooth-box (and smooth-box Student-t) priors on several dimensions that fall in different
+    regions: the reference broadcasts the per-class normaliser against the subset outside / inside
+    the box (gaussian_process.py:1346-1356, :1391-1413).  With two dimensions that counts terms
+    twice; with three it raises numpy's broadcasting ValueError.  Both are reproduced: values
+    bit-exact, and the exception where the reference raises."""
+    from gpyreg_amd import priors as pr
+
+    for tag in ("q0", "q1", "q2", "q3"):
+        hp = {k: g[tag + "_" + k] for k in ("mu", "sigma", "df", "a", "b")}
+        lb, ub, norm = g[tag + "_lb"], g[tag + "_ub"], g[tag + "_norm"]
+        assert np.allclose(pr.normalization_constants(hp, lb, ub), norm, rtol=1e-12, equal_nan=True)
+        H, lp, dlp, raised = g[tag + "_H"], g[tag + "_lp"], g[tag + "_dlp"], g[tag + "_raised"]
+        assert raised.any() == (tag in ("q0", "q1"))
+        for r in range(H.shape[0]):
+            if raised[r]:
+                with pytest.raises(ValueError):
+                    pr.log_priors(H[r], hp, lb, ub, norm, True)
+            else:
+                a, b = pr.log_priors(H[r], hp, lb, ub, norm, True)
+                assert a == lp[r] and np.array_equal(b, dlp[r], equal_nan=True), (tag, r, a, lp[r])
+
+
 def test_design_matches_reference_under_same_seed(g):
     for idx, name in enumerate(g["names"]):
         tag = str(name).split("|")[0]
