@@ -58,6 +58,7 @@ struct GemmArgs {
   int klo, khi, lower_only;
   int tiles_m, tiles_n;
   int flags = 0;       // GPC_GEMM_FLAGS: 8 = XCD-affine tile queues in persistent launches
+  int reserve = 0;     // persistent launches: CUs per XCD this launch stays off (0, 2 or 4), see gemm_persist_kernel
   int* ctr = nullptr;  // persistent launches: zeroed device counters the blocks draw tiles from
   int ntiles = 0, batch = 0;
 };
@@ -402,6 +403,19 @@ template <typename T, bool AKM, bool BKM, int BT, int NW>
 __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_persist_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) T smem[4 * opsz_of<T>(BT)];
   __shared__ int next_tile;
+  if (g.reserve) {
+    // CU reservation without CU-masked queues: a block that finds itself on a reserved CU (the last CU of
+    // shader engines 0 and 2 of its XCD; with reserve = 4 also of engines 1 and 3) returns at once.  The grid is
+    // oversized by the caller, the surplus drains through the reserved CUs in microseconds, and those CUs
+    // stay EMPTY for the whole launch: the latency-bound kernels of another stream (128 x 128 leaves,
+    // deep-level products) run there at full speed while this launch streams on the other CUs.
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    const unsigned cu = (hw >> 8) & 0xf, se = (hw >> 13) & 0x7;
+    const unsigned idx = (se & 1) ? cu - 1 : cu;  // engines 1, 3 number their CUs 1..8 (tools/cumask_probe.hip)
+    // reserve = 2: last CU of engines 0 and 2; 4: last CU of every engine; 8: last two; 12: last three
+    if (g.reserve == 2 ? (idx == 7 && (se & 1) == 0) : idx + (unsigned)(g.reserve / 4) >= 8u) return;
+  }
   if (!(g.flags & 8)) {
     const int total = g.ntiles * g.batch;
     for (;;) {
@@ -448,7 +462,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_persist_kernel(GemmArgs 
 inline int g_persist_spare = 0;     // tunable: GPC_PERSIST_SPARE (block slots a persistent launch leaves free)
 inline int g_block_slots = 512;     // two 128-tile blocks per CU (set from the device's CU count)
 template <typename T, int BT, int NW>
-inline hipError_t launch_gemm_bt(hipStream_t st, GemmArgs g, bool akm, bool bkm, int batch, int* ctr = nullptr) {
+inline hipError_t launch_gemm_bt(hipStream_t st, GemmArgs g, bool akm, bool bkm, int batch, int* ctr = nullptr,
+                                 int reserve = 0) {
   const int tm = g.M / BT, tn = g.N / BT;
   g.tiles_m = tm;
   g.tiles_n = tn;
@@ -460,8 +475,9 @@ inline hipError_t launch_gemm_bt(hipStream_t st, GemmArgs g, bool akm, bool bkm,
   g.ctr = ctr;
   const unsigned dyn = 0u;
   const int cap = g_block_slots - g_persist_spare;
-  if (ctr && BT == 128 && cap > 0 && (long long)ntiles * batch > cap) {
-    dim3 grid(cap), block(64 * NW);
+  g.reserve = reserve;
+  if (ctr && BT == 128 && cap > 0 && ((long long)ntiles * batch > cap || reserve)) {
+    dim3 grid(reserve ? cap + 96 : cap), block(64 * NW);
     if (!akm && !bkm)
       hipLaunchKernelGGL((gemm_persist_kernel<T, false, false, 128, NW>), grid, block, dyn, st, g);
     else if (!akm && bkm)
@@ -490,12 +506,12 @@ inline hipError_t launch_gemm_bt(hipStream_t st, GemmArgs g, bool akm, bool bkm,
 inline int g_small_launch_blocks = 1100;  // tunable: GPC_SMALL_BLOCKS
 template <typename T>
 inline hipError_t launch_gemm(hipStream_t st, GemmArgs g, bool akm, bool bkm, int batch, int force_bt = 0,
-                             int* ctr = nullptr) {
+                             int* ctr = nullptr, int reserve = 0) {
   const int tm = g.M / TILE, tn = g.N / TILE;
   const long long blocks128 = (long long)(g.lower_only ? tm * (tm + 1) / 2 : tm * tn) * batch;
   const bool small = force_bt ? (force_bt == 64) : (blocks128 < g_small_launch_blocks);
-  if (small) return launch_gemm_bt<T, 64, 4>(st, g, akm, bkm, batch);
-  return launch_gemm_bt<T, 128, 4>(st, g, akm, bkm, batch, ctr);
+  if (small && !(reserve && ctr)) return launch_gemm_bt<T, 64, 4>(st, g, akm, bkm, batch);
+  return launch_gemm_bt<T, 128, 4>(st, g, akm, bkm, batch, ctr, ctr ? reserve : 0);
 }
 
 // algorithmic flops of one launch (for the roofline bookkeeping)

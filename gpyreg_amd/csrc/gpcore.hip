@@ -144,6 +144,13 @@ struct gpc_ctx {
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   static constexpr int MAXG = 8;
   hipStream_t gst[MAXG] = {};  // sample-group streams
+  hipStream_t sst[MAXG + 1] = {};  // side streams of the deferred inverse products (plan.h), one per group + main
+  static constexpr int NDEV = 16;
+  hipEvent_t dev_ev[MAXG + 1][NDEV] = {};
+  // GPC_DEFER_MIN: node size from which U = T21 W11 runs on the side stream (0 off, -1 auto: the top two
+  // levels when the batch is small enough for latency-bound phases to matter); GPC_DEFER_RESERVE: CUs per
+  // XCD the deferred launch keeps empty (2, 4, 8, 12)
+  int defer_min = -1, defer_reserve = 8;
   hipEvent_t ev_up = nullptr, ev_done[MAXG] = {};
   int groups = 2;
   hipEvent_t ev_l0[MAXG + 1] = {}, ev_l1[MAXG + 1] = {};  // around the lauum launch of each group
@@ -492,6 +499,13 @@ struct Pipe {
     F.logdet = d_logdet;
     F.info = d_info;
     F.nvalid = N;
+    if (defer_node > 0 && !c->capturing && gpc::g_persist_spare >= 0) {
+      F.side = c->sst[gidx];
+      F.evs = c->dev_ev[gidx];
+      F.nev = gpc_ctx::NDEV;
+      F.defer_min = defer_node;
+      F.reserve = c->defer_reserve;
+    }
     if (gpc::g_persist_spare >= 0) {
       F.ctr = c->tile_ctr.as<int>() + (size_t)gidx * gpc_ctx::CTR_PER_GROUP;
       F.ctr_cap = gpc_ctx::CTR_PER_GROUP;
@@ -608,6 +622,7 @@ struct Pipe {
 
   int chunk_cnt = 0;
   int chunk_s0 = 0;  // first sample (batch numbering) of the chunk being processed
+  int defer_node = 0;  // plan.h: nodes at least this large run their U product on the side stream (0: none)
   int lauum_n[gpc_ctx::MAXG + 1] = {};
 
   // run the device pipeline for samples [s0, s0+cnt) whose matrices start at slot `slot`.
@@ -681,6 +696,19 @@ struct Pipe {
     hc.lap("h2d");
     int groups = c->groups;
     if (cnt < 2 * groups || npad < 1024 || kmode()) groups = 1;
+    // Deferred inverse products (plan.h): measured on MI355X (tools/defer_sweep.py) they pay whenever the
+    // latency-bound phases are a visible share of the batch -- S (npad/4096)^3 <= 24 with at least 4 samples:
+    // N=2048 S=16 4.70 -> 4.05 ms, N=4096 S=4 8.46 -> 7.35, N=4096 S=16 21.5 -> 20.8 -- and cost a little
+    // beyond (N=8192 S=64: 556 -> 584 ms).  With them one sample group is better than two.
+    defer_node = 0;
+    if (mode != MODE_NLL && c->defer_min != 0) {
+      const double work = (double)cnt * std::pow((double)npad / 4096.0, 3.0);
+      if (c->defer_min > 0)
+        defer_node = c->defer_min;
+      else if (cnt >= 4 && npad >= 2048 && work <= 24.0)
+        defer_node = (npad / 2 / TILE) * TILE;
+      if (defer_node > 0) groups = 1;
+    }
     if (groups == 1 && c->graph_max_npad > 0 && npad <= c->graph_max_npad && !kmode()) {
       int rc = graph_section(cnt);
       if (rc) return rc;
@@ -1598,6 +1626,13 @@ int gpc_create(int device, gpc_ctx** out) {
   for (int g = 0; g < gpc_ctx::MAXG && ok; ++g)
     ok = hipStreamCreateWithPriority(&c->gst[g], hipStreamNonBlocking, prio_hi) == hipSuccess &&
          hipEventCreateWithFlags(&c->ev_done[g], hipEventDisableTiming) == hipSuccess;
+  for (int g = 0; g <= gpc_ctx::MAXG && ok; ++g) {
+    ok = hipStreamCreateWithPriority(&c->sst[g], hipStreamNonBlocking, prio_lo) == hipSuccess;
+    for (int i = 0; i < gpc_ctx::NDEV && ok; ++i)
+      ok = hipEventCreateWithFlags(&c->dev_ev[g][i], hipEventDisableTiming) == hipSuccess;
+  }
+  if (const char* e = getenv("GPC_DEFER_MIN")) c->defer_min = atoi(e);
+  if (const char* e = getenv("GPC_DEFER_RESERVE")) c->defer_reserve = atoi(e);
   if (!ok) {
     g_create_err = "creating the sample-group streams failed";
     delete c;
@@ -1639,6 +1674,11 @@ void gpc_destroy(gpc_ctx* c) {
   for (int g = 0; g <= gpc_ctx::MAXG; ++g) {
     if (c->ev_l0[g]) (void)hipEventDestroy(c->ev_l0[g]);
     if (c->ev_l1[g]) (void)hipEventDestroy(c->ev_l1[g]);
+  }
+  for (int g = 0; g <= gpc_ctx::MAXG; ++g) {
+    for (int i = 0; i < gpc_ctx::NDEV; ++i)
+      if (c->dev_ev[g][i]) (void)hipEventDestroy(c->dev_ev[g][i]);
+    if (c->sst[g]) (void)hipStreamDestroy(c->sst[g]);
   }
   for (int g = 0; g < gpc_ctx::MAXG; ++g) {
     if (c->ev_done[g]) (void)hipEventDestroy(c->ev_done[g]);
@@ -2018,6 +2058,10 @@ int gpc_set_option(gpc_ctx* c, const char* name, int value) {
     gpc::g_small_launch_blocks = value;
   else if (n == "leaf")
     gpc::g_leaf_version = value;
+  else if (n == "defer_min")  // deferred inverse products: node size from which U runs on the side stream (0 off, -1 auto)
+    c->defer_min = value;
+  else if (n == "defer_reserve")
+    c->defer_reserve = value;
   else if (n == "start_mult_log10")  // test hook: first jitter multiplier 10^value
     c->start_mult = std::pow(10.0, std::max(0, std::min(9, value)));
   else if (n == "append_fail_mask")  // test hook: samples whose rank-one append is declared unstable

@@ -38,6 +38,14 @@ struct Factor {
   // zeroed device counters for persistent GEMM launches (gemm.h); one per launch, in order
   int* ctr = nullptr;
   int ctr_cap = 0, ctr_used = 0;
+  // Deferred inverse products (GPC_DEFER_MIN > 0): U = T21 * W11 of a node of size >= defer_min does not depend
+  // on the node's right child, whose factorization starts with latency-bound work (leaves, deep levels).  U is
+  // launched on `side` as a persistent GEMM that keeps `reserve` CUs per XCD empty (gemm.h), the right child
+  // proceeds on `st` (its small kernels land on the empty CUs), and W21 = -W22 * U joins the two.
+  hipStream_t side = nullptr;
+  hipEvent_t* evs = nullptr;  // pool of events for the fork / join pairs
+  int nev = 0, ev_used = 0;
+  int defer_min = 0, reserve = 0;
   double flops = 0;      // algorithmic flops issued (tile-exact)
   int launches = 0;
   hipError_t err = hipSuccess;
@@ -46,7 +54,7 @@ struct Factor {
 
   void gemm(T* C, long long sC, const T* Aop, long long sAop, const T* Bop, long long sBop, int M,
             int N, int K, bool akm, bool bkm, double alpha, int beta, int klo, int khi, int lower,
-            hipStream_t on = nullptr) {
+            hipStream_t on = nullptr, int rsv = 0) {
     GemmArgs g;
     g.A = Aop;
     g.B = Bop;
@@ -71,7 +79,7 @@ struct Factor {
       slot = ctr + ctr_used;
       ctr_used += NQ;
     }
-    hipError_t e = launch_gemm<T>(on ? on : st, g, akm, bkm, batch, 0, slot);
+    hipError_t e = launch_gemm<T>(on ? on : st, g, akm, bkm, batch, 0, slot, rsv);
     if (e != hipSuccess && err == hipSuccess) err = e;
   }
 
@@ -103,11 +111,26 @@ struct Factor {
     // 3. A22 -= T21 * T21^T
     gemm(blk(A, o2, o2), sA, blk(Tm, o2, o1), sT, blk(Tm, o2, o1), sT, n2, n2, n1, false, false, -1.0,
          1, KLO_ZERO, KHI_FULL, 1);
+    const bool defer = need_inv && side && defer_min > 0 && n >= defer_min && ev_used + 2 <= nev;
+    hipEvent_t ev_join = nullptr;
+    if (defer) {
+      // 5a early, on the side stream: U = T21 * W11 -> A21 (reads T21, W11: untouched by the right child)
+      hipEvent_t ev_fork = evs[ev_used++];
+      ev_join = evs[ev_used++];
+      chk(hipEventRecord(ev_fork, st));
+      chk(hipStreamWaitEvent(side, ev_fork, 0));
+      gemm(blk(A, o2, o1), sA, blk(Tm, o2, o1), sT, blk(W, o1, o1), sW, n2, n1, n1, false, true, 1.0, 0,
+           KLO_COL, KHI_FULL, 0, side, reserve);
+      chk(hipEventRecord(ev_join, side));
+    }
     potrf_inv(o2, n2, need_inv, keep_L);
     if (need_inv) {
       // 5a. U = T21 * W11  -> A21
-      gemm(blk(A, o2, o1), sA, blk(Tm, o2, o1), sT, blk(W, o1, o1), sW, n2, n1, n1, false, true, 1.0, 0,
-           KLO_COL, KHI_FULL, 0);
+      if (defer)
+        chk(hipStreamWaitEvent(st, ev_join, 0));
+      else
+        gemm(blk(A, o2, o1), sA, blk(Tm, o2, o1), sT, blk(W, o1, o1), sW, n2, n1, n1, false, true, 1.0, 0,
+             KLO_COL, KHI_FULL, 0);
       // 5b. W21 = -W22 * U
       gemm(blk(W, o2, o1), sW, blk(W, o2, o2), sW, blk(A, o2, o1), sA, n2, n1, n2, false, true, -1.0,
            0, KLO_ZERO, KHI_ROW, 0);
