@@ -144,14 +144,18 @@ def cpu_baseline(cfg_idx, gpu_nlz0=None, gpu_dnlz0=None):
         one = float(json.loads(r.stdout.strip().splitlines()[-1])[0])
     except Exception:  # noqa: BLE001 - the 1-thread figure is optional
         one = None
-    out = dict(value=1.0 / med, unit="fit-evals/s", cores=os.cpu_count(), kind="port",
+    host = _host_description()
+    blas_threads = max([b.get("num_threads") or 1 for b in host["blas"]] or [1])
+    # `cores` = the threads the evaluation can actually use: the BLAS pool (NumPy's elementwise passes, which
+    # dominate, are single-threaded); the logical CPU count is in host.logical_cpus
+    out = dict(value=1.0 / med, unit="fit-evals/s", cores=blas_threads, kind="port",
                sample=f"sample 0 of {c['S']}, {'NLL+grad' if grad else 'NLL only (fp64)'}, N={c['N']} D={c['D']} "
                       f"{c['kernel']}{c['degree'] or ''}: {'1 warm-up + median of 3 evaluations' if full else '1 evaluation'} "
                       f"({', '.join('%.2f' % t for t in times)} s), default BLAS threading",
                seconds_per_eval=med,
                single_thread={"value": None if one is None else 1.0 / one, "seconds_per_eval": one,
                               "how": "child process, OPENBLAS/OMP/MKL_NUM_THREADS=1, one evaluation"},
-               host=_host_description(), nlz=float(nlz))
+               host=host, nlz=float(nlz))
     if gpu_nlz0 is not None:
         out["nlz_rel_err"] = float(abs(gpu_nlz0 - nlz) / max(1.0, abs(nlz)))
     if gpu_dnlz0 is not None:
