@@ -1650,7 +1650,6 @@ int gpc_create(int device, gpc_ctx** out) {
   if (const char* e = getenv("GPC_SMALL_BLOCKS")) gpc::g_small_launch_blocks = atoi(e);
   if (const char* e = getenv("GPC_GEMM_FLAGS")) gpc::g_gemm_flags = atoi(e);
   if (const char* e = getenv("GPC_XCD_AFFINE")) gpc::g_gemm_flags = atoi(e) ? (gpc::g_gemm_flags | 8) : (gpc::g_gemm_flags & ~8);
-  if (const char* e = getenv("GPC_LEAF")) gpc::g_leaf_version = atoi(e);
   *out = c;
   return 0;
 }
@@ -2056,8 +2055,6 @@ int gpc_set_option(gpc_ctx* c, const char* name, int value) {
     c->groups = std::max(1, std::min((int)gpc_ctx::MAXG, value));
   else if (n == "small_blocks")
     gpc::g_small_launch_blocks = value;
-  else if (n == "leaf")
-    gpc::g_leaf_version = value;
   else if (n == "defer_min")  // deferred inverse products: node size from which U runs on the side stream (0 off, -1 auto)
     c->defer_min = value;
   else if (n == "defer_reserve")

@@ -5,19 +5,8 @@
 // block in A) and W = L^-1 (full 128 x 128 tile written to the W buffer, zeros above
 // the diagonal), plus sum(log diag L) and the LAPACK-style info flag.
 //
-// Two kernels: leaf3 (default, further down) is MFMA-blocked; leaf2 (GPC_LEAF=2) is the scalar
-// algorithm it replaced, kept as a cross-check: a right-looking elimination in which the
-// 128 x 128 block lives in REGISTERS (each of the 256 threads owns an 8 x 8 set of entries,
-// cyclically distributed: rows ty+16a, cols tx+16b) and only the pivot columns and pivot rows
-// travel through LDS (two pivots per barrier).
-// The same rank-1 update that eliminates column j of the Cholesky factor also
-// advances the forward substitution L W = I, in place:
-//     rows i > j :  M[i][k] -= c[i] * v[k]
-//        c[i] = L[i][j]                      (pivot column / sqrt(pivot))
-//        v[k] = L[k][j]   for k > j           -> Schur complement of the SPD block
-//        v[k] = W[j][k]   for k <= j          -> W[i][k] accumulates -sum L[i][j] W[j][k]
-// Columns k <= j of the register block no longer hold A (their L values have been
-// written out) so they are reused for W: after 128 steps the registers hold W.
+// leaf3 is MFMA-blocked (16-wide panels, the block held as accumulator tiles).  The scalar elimination it
+// replaced (84 us per leaf against 46 us; two pivots per barrier) was removed in round 2.
 #pragma once
 #include "common.h"
 
@@ -37,213 +26,6 @@ __device__ __forceinline__ float fast_rsqrt(float x) {
   float r = __builtin_amdgcn_rsqf(x);
   r = r * (1.5f - 0.5f * x * r * r);
   return r;
-}
-
-// =====================================================================================
-// leaf2: in-register elimination, TWO pivots per barrier.
-//
-// Per pair of columns (j0, j1 = j0+1) the owners publish the two raw pivot columns and
-// the two raw pivot rows; every thread redundantly factors the 2x2 pivot block
-//     [p00  . ]        d0 = sqrt(p00), l10 = p10/d0, d1 = sqrt(p11 - l10^2)
-//     [p10 p11]        inverse of [[d0,0],[l10,d1]] = [[r0,0],[w10,r1]], w10 = -l10 r0 r1
-// and applies the rank-2 update  M[i][k] -= c0[i] v0[k] + c1[i] v1[k]  to rows i > j1:
-//     c0 = C0 r0,  c1 = (C1 - c0 l10) r1                 (columns of L)
-//     v0 = X0 r0,  v1 = (X1 - l10 v0) r1   with X = C (k > j1: Schur part)
-//                                              or R (k < j0: rows of W)
-//     inside the pair: v0[j0] = r0, v1[j0] = w10, v0[j1] = 0, v1[j1] = r1.
-// L is staged in LDS and written out once, coalesced.
-// =====================================================================================
-constexpr int LDL = TILE + 1;  // LDS stride of the staged L tile
-
-template <typename T, int JB>
-__device__ __forceinline__ void leaf2_steps(T (&M)[8][8], T* __restrict__ pub, T* __restrict__ dbuf,
-                                            T* __restrict__ Ls, int tx, int ty, int& bad, int nvalid) {
-#pragma clang loop unroll(disable)
-  for (int jj = 0; jj < 16; jj += 2) {
-    const int j0 = JB * 16 + jj, j1 = j0 + 1;
-    if (j0 >= nvalid) break;  // the rest of the tile is identity padding: nothing to eliminate
-    T* C0 = pub + ((jj >> 1) & 1) * 4 * TILE;
-    T* C1 = C0 + TILE;
-    T* R0 = C1 + TILE;
-    T* R1 = R0 + TILE;
-    if (tx == jj) {
-#pragma unroll
-      for (int a = 0; a < 8; ++a) C0[ty + 16 * a] = M[a][JB];
-    }
-    if (tx == jj + 1) {
-#pragma unroll
-      for (int a = 0; a < 8; ++a) C1[ty + 16 * a] = M[a][JB];
-    }
-    if (ty == jj) {
-#pragma unroll
-      for (int b = 0; b < 8; ++b) R0[tx + 16 * b] = M[JB][b];
-    }
-    if (ty == jj + 1) {
-#pragma unroll
-      for (int b = 0; b < 8; ++b) R1[tx + 16 * b] = M[JB][b];
-    }
-    __syncthreads();
-    const T p00 = C0[j0], p10 = C0[j1], p11 = C1[j1];
-    const T r0 = fast_rsqrt(p00);
-    const T d0 = p00 * r0;
-    const T l10 = p10 * r0;
-    const T s11 = fma(-l10, l10, p11);
-    const T r1 = fast_rsqrt(s11);
-    const T d1 = s11 * r1;
-    const T w10 = -(l10 * r0) * r1;
-    if (bad == 0) {
-      if (!(p00 > (T)0))
-        bad = j0 + 1;
-      else if (!(s11 > (T)0))
-        bad = j1 + 1;
-    }
-    if (tx == jj && ty == jj) {
-      dbuf[j0] = d0;
-      dbuf[j1] = d1;
-    }
-
-    T c0[8], c1[8], v0[8], v1[8];
-#pragma unroll
-    for (int a = JB; a < 8; ++a) {
-      const int i = ty + 16 * a;
-      c0[a] = C0[i] * r0;
-      c1[a] = fma(-c0[a], l10, C1[i]) * r1;
-    }
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      const int k = tx + 16 * b;
-      T x0, x1;
-      if (b > JB) {
-        x0 = C0[k];
-        x1 = C1[k];
-      } else if (b < JB) {
-        x0 = R0[k];
-        x1 = R1[k];
-      } else {
-        const bool right = tx > jj + 1;
-        x0 = right ? C0[k] : R0[k];
-        x1 = right ? C1[k] : R1[k];
-      }
-      T a0 = x0 * r0;
-      T a1 = fma(-l10, a0, x1) * r1;
-      if (b == JB) {
-        if (tx == jj) {
-          a0 = r0;
-          a1 = w10;
-        } else if (tx == jj + 1) {
-          a0 = (T)0;
-          a1 = r1;
-        }
-      }
-      v0[b] = a0;
-      v1[b] = a1;
-    }
-    // owners of the two pivot columns: stage L, recycle the registers for W
-    if (tx == jj || tx == jj + 1) {
-      const bool first = (tx == jj);
-      const int jc = first ? j0 : j1;
-#pragma unroll
-      for (int a = JB; a < 8; ++a) {
-        const int i = ty + 16 * a;
-        if (i > j1) {
-          Ls[i * LDL + jc] = first ? c0[a] : c1[a];
-          M[a][JB] = (T)0;
-        } else if (i == j1) {
-          Ls[i * LDL + jc] = first ? l10 : d1;
-        } else if (i == j0 && first) {
-          Ls[i * LDL + jc] = d0;
-        }
-      }
-    }
-    // rank-2 update of every row below the pair
-#pragma unroll
-    for (int a = JB; a < 8; ++a) {
-      const bool active = (a > JB) || (ty > jj + 1);
-      if (active) {
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-          if (b > JB && b > a) continue;  // strictly-upper blocks of the Schur part are never read
-          M[a][b] = fma(-c1[a], v1[b], fma(-c0[a], v0[b], M[a][b]));
-        }
-      }
-    }
-    // the two pivot rows become rows j0, j1 of W
-    if (ty == jj) {
-#pragma unroll
-      for (int b = 0; b < 8; ++b) M[JB][b] = (tx + 16 * b <= j0) ? v0[b] : (T)0;
-    }
-    if (ty == jj + 1) {
-#pragma unroll
-      for (int b = 0; b < 8; ++b) M[JB][b] = (tx + 16 * b <= j1) ? v1[b] : (T)0;
-    }
-  }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void leaf2_kernel(T* __restrict__ A, long long sA, int lda,
-                                                    T* __restrict__ W, long long sW, int ldw, int off,
-                                                    double* __restrict__ logdet, int* __restrict__ info,
-                                                    int nvalid) {
-  __shared__ T Ls[TILE * LDL];
-  __shared__ T pub[8 * TILE];
-  __shared__ T dbuf[TILE];
-  __shared__ double red4[4];
-  const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
-  T* Ab = A + (size_t)blockIdx.x * sA;
-  T* Wb = W + (size_t)blockIdx.x * sW;
-
-  T M[8][8];
-#pragma unroll
-  for (int a = 0; a < 8; ++a)
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      const int i = ty + 16 * a, k = tx + 16 * b;
-      M[a][b] = (k <= i) ? Ab[(size_t)i * lda + k] : (T)0;
-    }
-
-  // columns >= nvalid (rounded up to a pivot pair) are identity padding: their L column is
-  // e_j, their pivot is 1, and the registers already hold the matching rows/columns of W = I
-  const int nelim = min(TILE, (nvalid + 1) & ~1);
-  if (nelim < TILE) {
-#pragma unroll
-    for (int a = 0; a < 8; ++a)
-#pragma unroll
-      for (int b = 0; b < 8; ++b) {
-        const int i = ty + 16 * a, k = tx + 16 * b;
-        if (k >= nelim && k <= i) Ls[i * LDL + k] = (i == k) ? (T)1 : (T)0;
-      }
-    if (t >= nelim && t < TILE) dbuf[t] = (T)1;
-  }
-  int bad = 0;
-  leaf2_steps<T, 0>(M, pub, dbuf, Ls, tx, ty, bad, nelim);
-  if (nelim > 16) leaf2_steps<T, 1>(M, pub, dbuf, Ls, tx, ty, bad, nelim);
-  if (nelim > 32) leaf2_steps<T, 2>(M, pub, dbuf, Ls, tx, ty, bad, nelim);
-  if (nelim > 48) leaf2_steps<T, 3>(M, pub, dbuf, Ls, tx, ty, bad, nelim);
-  if (nelim > 64) leaf2_steps<T, 4>(M, pub, dbuf, Ls, tx, ty, bad, nelim);
-  if (nelim > 80) leaf2_steps<T, 5>(M, pub, dbuf, Ls, tx, ty, bad, nelim);
-  if (nelim > 96) leaf2_steps<T, 6>(M, pub, dbuf, Ls, tx, ty, bad, nelim);
-  if (nelim > 112) leaf2_steps<T, 7>(M, pub, dbuf, Ls, tx, ty, bad, nelim);
-
-#pragma unroll
-  for (int a = 0; a < 8; ++a)
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      const int i = ty + 16 * a, k = tx + 16 * b;
-      Wb[(size_t)i * ldw + k] = M[a][b];
-    }
-  __syncthreads();
-#pragma unroll
-  for (int a = 0; a < 8; ++a)
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      const int i = ty + 16 * a, k = tx + 16 * b;
-      if (b <= a && k <= i) Ab[(size_t)i * lda + k] = Ls[i * LDL + k];
-    }
-  const double lg = block_sum_256(t < TILE ? log((double)dbuf[t]) : 0.0, red4);
-  if (t == 0) {
-    if (bad) atomicCAS(info + blockIdx.x, 0, off + bad);
-    atomicAdd(logdet + blockIdx.x, lg);
-  }
 }
 
 // ---- leaf3: MFMA-blocked 128 x 128 Cholesky + inverse ----------------------------------------
@@ -521,6 +303,6 @@ __global__ __launch_bounds__(256, GPC_LEAF3_WPS) void leaf3_kernel(T* __restrict
   }
 }
 
-inline int g_leaf_version = 3;  // GPC_LEAF: 2 scalar elimination by pivot pairs, 3 MFMA-blocked (default)
+inline int g_leaf_version = 3;  // kept for the launch-graph key; one leaf kernel exists
 
 }  // namespace gpc

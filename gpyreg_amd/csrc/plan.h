@@ -89,14 +89,9 @@ struct Factor {
 
   void potrf_inv(int off, int n, bool need_inv, bool keep_L) {
     if (n == TILE) {
-      if (g_leaf_version == 3)
-        hipLaunchKernelGGL((leaf3_kernel<T>), dim3(batch), dim3(256), 0, st, blk(A, off, off), sA, npad,
-                           blk(W, off, off), sW, npad, off, logdet, info,
-                           std::max(0, std::min(TILE, nvalid - off)));
-      else
-        hipLaunchKernelGGL((leaf2_kernel<T>), dim3(batch), dim3(256), 0, st, blk(A, off, off), sA, npad,
-                           blk(W, off, off), sW, npad, off, logdet, info,
-                           std::max(0, std::min(TILE, nvalid - off)));
+      hipLaunchKernelGGL((leaf3_kernel<T>), dim3(batch), dim3(256), 0, st, blk(A, off, off), sA, npad,
+                         blk(W, off, off), sW, npad, off, logdet, info,
+                         std::max(0, std::min(TILE, nvalid - off)));
       flops += (2.0 / 3.0) * TILE * (double)TILE * TILE * batch;
       ++launches;
       return;

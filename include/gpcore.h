@@ -173,11 +173,13 @@ int gpc_last_timing(gpc_ctx* ctx, double* ms_total, double* ms_factor);
  * (samples in that launch x N^3/3).                                                     */
 int gpc_last_lauum_timing(gpc_ctx* ctx, double* ms, double* flops);
 /* Tuning switches (also settable through the environment at gpc_create: GPC_GROUPS,
- * GPC_SMALL_BLOCKS, GPC_LEAF): "groups" = sample groups on separate HIP
- * streams (1..8), "small_blocks" = launch size below which 64x64 tiles are used,
- * "leaf" = 2 (scalar) | 3 (MFMA-blocked, default).  Test hooks: "start_mult_log10" = k starts
- * the jitter escalation of every factorization at 10^k instead of 1 (gaussian_process.py:2402),
- * "append_fail_mask" = bit s declares the rank-one append of sample s unstable (:789-798).       */
+ * GPC_SMALL_BLOCKS, GPC_DEFER_MIN, GPC_DEFER_RESERVE): "groups" = sample groups on separate HIP
+ * streams (1..8), "small_blocks" = launch size below which 64x64 tiles are used, "defer_min" = node
+ * size from which the inverse product U = T21 W11 runs on a side stream (0 off, -1 auto),
+ * "defer_reserve" = CUs per XCD that launch keeps empty (2 | 4 | 8 | 12).  Test hooks:
+ * "start_mult_log10" = k starts the jitter escalation of every factorization at 10^k instead of 1
+ * (gaussian_process.py:2402), "append_fail_mask" = bit s declares the rank-one append of sample s
+ * unstable (:789-798).                                                                            */
 int gpc_set_option(gpc_ctx* ctx, const char* name, int value);
 /* fp64/fp32 MFMA issue-rate microbenchmark: achieved TFLOP/s of a register-resident
  * v_mfma_{f64,f32}_16x16x4 loop on all CUs (2 waves per SIMD), the shader cycles one
