@@ -226,3 +226,31 @@ def test_mid_size_every_kernel_family_against_the_oracle(kernel, degree, noise):
         scale = np.maximum(np.abs(rd[m]), np.abs(rd[m]).max())
         assert (np.abs(dnlz[s][m] - rd[m]) <= 1e-8 * scale).all(), (kernel, s)
         assert (np.abs(dnlz32[s][m] - rd[m]) <= 1e-3 * scale).all(), (kernel, s, "f32")
+
+
+def test_deferred_inverse_products_do_not_change_a_bit():
+    """plan.h's deferred U = T21 W11 (side stream, CU-reserving persistent launch) reorders launches, not
+    arithmetic: NLL, gradient and posteriors with the schedule forced on (every node >= 512), automatic and
+    off must be identical bit for bit (N = 2304: odd splits; S = 6 and 16)."""
+    import bench
+    from gpyreg_amd import _lib
+
+    ctx = _lib.context(0)
+    bench_cfg = dict(bench.CONFIGS[3])
+    try:
+        bench.CONFIGS[3] = dict(bench_cfg, N=2304)
+        for S in (6, 16):
+            X, y, hyp = bench.synthetic_problem(3, S)
+            xs = X[:33] + 0.01
+            res = []
+            for dmin in (0, -1, 512):
+                ctx.set_option("defer_min", dmin)
+                gp = bench.make_gp(3, "f64")
+                gp.update(X_new=X, y_new=y, hyp=hyp)
+                res.append(gp.nll_batch(hyp, compute_grad=True) + gp.predict(xs, separate_samples=True))
+            for r in res[1:]:
+                for a, b in zip(res[0], r):
+                    assert np.array_equal(a, b)
+    finally:
+        bench.CONFIGS[3] = bench_cfg
+        ctx.set_option("defer_min", -1)
