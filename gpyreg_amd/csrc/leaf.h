@@ -156,9 +156,6 @@ __device__ __forceinline__ void leaf3_panel(typename MM<T>::acc_t (&S)[2][8], T*
 #if defined(GPC_LEAF3_NODIAG)  // timing experiment only: results are wrong
 #pragma unroll
   for (int i = 0; i < 16; ++i) wv[i] = (l15 == i) ? (T)1 : (T)0;
-#elif defined(GPC_DIAG16_ONE_ROW)
-  // only the first row of 16 lanes is ever read afterwards (myW, the diagonal block of L, badk)
-  if (lq == 0) diag16<T>(d, wv, l15, badk);
 #else
   diag16<T>(d, wv, l15, badk);
 #endif
