@@ -231,16 +231,13 @@ __device__ __forceinline__ void lower_tile(int bx, int& ti, int& tj) {
 // grid = (lower tiles of npad/64, batch)
 // ---------------------------------------------------------------------------------
 template <typename T, int KIND, int DEG>
-__global__ __launch_bounds__(256) void build_kernel(CovDesc cd, const double* __restrict__ Xs_all,
-                                                    const double* __restrict__ sp_all,
-                                                    const double* __restrict__ dvec_all, int n,
-                                                    int npad, T* __restrict__ A_all, long long sA,
-                                                    int lda) {
-  __shared__ double xi[CT][DCH + 1];
-  __shared__ double xj[CT][DCH + 1];
-  const int t = threadIdx.x, tx = t & 15, ty = t >> 4, b = blockIdx.y;
+__device__ __forceinline__ void build_tile(const CovDesc& cd, const double* __restrict__ Xs_all,
+                                           const double* __restrict__ sp_all, const double* __restrict__ dvec_all,
+                                           int n, int npad, T* __restrict__ A_all, long long sA, int lda, int tile,
+                                           int b, double (*xi)[DCH + 1], double (*xj)[DCH + 1]) {
+  const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
   int ti, tj;
-  lower_tile(blockIdx.x, ti, tj);
+  lower_tile(tile, ti, tj);
   const int i0 = ti * CT, j0 = tj * CT;
   const double* Xs = Xs_all + (size_t)b * npad * cd.D;
   const double* sp = sp_all + (size_t)b * SP_STRIDE;
@@ -267,6 +264,50 @@ __global__ __launch_bounds__(256) void build_kernel(CovDesc cd, const double* __
       }
       A[(size_t)i * lda + j] = (T)v;
     }
+}
+
+// grid = (number of lower tiles to build, batch); tile0 = index of the first one
+template <typename T, int KIND, int DEG>
+__global__ __launch_bounds__(256) void build_kernel(CovDesc cd, const double* __restrict__ Xs_all,
+                                                    const double* __restrict__ sp_all,
+                                                    const double* __restrict__ dvec_all, int n,
+                                                    int npad, T* __restrict__ A_all, long long sA,
+                                                    int lda, int tile0) {
+  __shared__ double xi[CT][DCH + 1];
+  __shared__ double xj[CT][DCH + 1];
+  build_tile<T, KIND, DEG>(cd, Xs_all, sp_all, dvec_all, n, npad, A_all, sA, lda, tile0 + blockIdx.x, blockIdx.y, xi,
+                           xj);
+}
+
+// The tail of the build (tiles tile0 .. ntiles-1 of every sample) as a persistent launch that stays off the
+// same reserved CUs as a deferred GEMM (gemm.h: blocks that land on one return at once): it runs on a side
+// stream UNDER the factorization of the first rows, whose leaves need whole empty CUs.  ctr: zeroed counter.
+template <typename T, int KIND, int DEG>
+__global__ __launch_bounds__(256) void build_persist_kernel(CovDesc cd, const double* __restrict__ Xs_all,
+                                                            const double* __restrict__ sp_all,
+                                                            const double* __restrict__ dvec_all, int n, int npad,
+                                                            T* __restrict__ A_all, long long sA, int lda, int tile0,
+                                                            int ntiles, int batch, int reserve, int* ctr) {
+  __shared__ double xi[CT][DCH + 1];
+  __shared__ double xj[CT][DCH + 1];
+  __shared__ int next;
+  if (reserve) {
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    const unsigned cu = (hw >> 8) & 0xf, se = (hw >> 13) & 0x7;
+    const unsigned idx = (se & 1) ? cu - 1 : cu;
+    if (reserve == 2 ? (idx == 7 && (se & 1) == 0) : idx + (unsigned)(reserve / 4) >= 8u) return;
+  }
+  const int total = (ntiles - tile0) * batch;
+  for (;;) {
+    if (threadIdx.x == 0) next = atomicAdd(ctr, 1);
+    __syncthreads();
+    const int idx = __builtin_amdgcn_readfirstlane(next);
+    __syncthreads();  // everyone holds idx before thread 0 overwrites it; also fences xi / xj between tiles
+    if (idx >= total) break;
+    build_tile<T, KIND, DEG>(cd, Xs_all, sp_all, dvec_all, n, npad, A_all, sA, lda, tile0 + idx / batch, idx % batch,
+                             xi, xj);
+  }
 }
 
 // Sum four per-lane values over the 64 lanes of a wave with 7 exchanges instead of 24: two

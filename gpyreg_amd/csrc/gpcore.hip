@@ -147,6 +147,7 @@ struct gpc_ctx {
   hipStream_t sst[MAXG + 1] = {};  // side streams of the deferred inverse products (plan.h), one per group + main
   static constexpr int NDEV = 16;
   hipEvent_t dev_ev[MAXG + 1][NDEV] = {};
+  hipEvent_t ev_bfork[MAXG + 1] = {}, ev_btail[MAXG + 1] = {};  // split kernel build (device_section)
   // GPC_DEFER_MIN: node size from which U = T21 W11 runs on the side stream (0 off, -1 auto: the top two
   // levels when the batch is small enough for latency-bound phases to matter); GPC_DEFER_RESERVE: CUs per
   // XCD the deferred launch keeps empty (2, 4, 8, 12)
@@ -464,6 +465,7 @@ struct Pipe {
     double* d_quad = c->scal.as<double>() + chunk_cnt + off;
     int* d_info = reinterpret_cast<int*>(c->scal.as<double>() + 2 * chunk_cnt) + off;
     const int t64 = npad / CT, ntl = t64 * (t64 + 1) / 2;
+    split_build = false;
     if (kmode()) {
       // A = K / (sn2_div * sn2_mult) + diag from the caller's matrix, one sample at a time through one
       // N x N staging buffer (stream order keeps the upload of sample i+1 behind the kernel reading i)
@@ -481,9 +483,28 @@ struct Pipe {
       dim3 grid((unsigned)((tot + 255) / 256), n);
       hipLaunchKernelGGL(scale_x_kernel, grid, dim3(256), 0, st, c->dX.as<double>(), N, npad, D,
                          c->mulb.as<double>() + (size_t)off * D, c->divb.as<double>() + (size_t)off * D, xs);
-      GPC_COV_DISPATCH(build_kernel, T, b.cd, dim3(ntl, n), dim3(256), 0, st, b.cd, (const double*)xs,
-                       (const double*)spb, (const double*)(c->dvec.as<double>() + (size_t)off * npad), N, npad, Ac, sM,
-                       npad);
+      // With the deferred schedule the build is split: the tiles of the first 1024 rows on this stream, the
+      // rest as a persistent, CU-reserving launch on the side stream under the first subtree (plan.h waits
+      // for it before the first launch that reads rows >= 1024).
+      const int head64 = 1024 / CT, ntl_head = head64 * (head64 + 1) / 2;
+      split_build = defer_node > 0 && !c->capturing && gpc::g_persist_spare >= 0 && npad >= 2048;
+      const double* dv = c->dvec.as<double>() + (size_t)off * npad;
+      if (split_build) {
+        GPC_COV_DISPATCH(build_kernel, T, b.cd, dim3(ntl_head, n), dim3(256), 0, st, b.cd, (const double*)xs,
+                         (const double*)spb, dv, N, npad, Ac, sM, npad, 0);
+        hipStream_t sd = c->sst[gidx];
+        int* bctr = c->tile_ctr.as<int>() + (size_t)gidx * gpc_ctx::CTR_PER_GROUP + gpc_ctx::CTR_PER_GROUP - 1;
+        HIPCHK(c, hipMemsetAsync(bctr, 0, sizeof(int), st));
+        HIPCHK(c, hipEventRecord(c->ev_bfork[gidx], st));
+        HIPCHK(c, hipStreamWaitEvent(sd, c->ev_bfork[gidx], 0));
+        GPC_COV_DISPATCH(build_persist_kernel, T, b.cd, dim3(4 * gpc::g_block_slots / 2 + 128), dim3(256), 0, sd, b.cd,
+                         (const double*)xs, (const double*)spb, dv, N, npad, Ac, sM, npad, ntl_head, ntl, n,
+                         c->defer_reserve, bctr);
+        HIPCHK(c, hipEventRecord(c->ev_btail[gidx], sd));
+      } else {
+        GPC_COV_DISPATCH(build_kernel, T, b.cd, dim3(ntl, n), dim3(256), 0, st, b.cd, (const double*)xs,
+                         (const double*)spb, dv, N, npad, Ac, sM, npad, 0);
+      }
     }
     HIPCHK(c, hipGetLastError());
 
@@ -506,10 +527,15 @@ struct Pipe {
       F.defer_min = defer_node;
       F.reserve = c->defer_reserve;
     }
+    if (split_build) {
+      F.ev_tail = c->ev_btail[gidx];
+      F.tail_row0 = 1024;
+    }
     if (gpc::g_persist_spare >= 0) {
+      // (the last counter of the group belongs to the split build, already in flight on the side stream)
       F.ctr = c->tile_ctr.as<int>() + (size_t)gidx * gpc_ctx::CTR_PER_GROUP;
-      F.ctr_cap = gpc_ctx::CTR_PER_GROUP;
-      HIPCHK(c, hipMemsetAsync(F.ctr, 0, gpc_ctx::CTR_PER_GROUP * sizeof(int), st));
+      F.ctr_cap = gpc_ctx::CTR_PER_GROUP - NQ;
+      HIPCHK(c, hipMemsetAsync(F.ctr, 0, (gpc_ctx::CTR_PER_GROUP - NQ) * sizeof(int), st));
     }
     // NLL only: the inverse of the whole matrix is not needed (only of left children)
     const bool full_inv = (mode != MODE_NLL);
@@ -623,6 +649,7 @@ struct Pipe {
   int chunk_cnt = 0;
   int chunk_s0 = 0;  // first sample (batch numbering) of the chunk being processed
   int defer_node = 0;  // plan.h: nodes at least this large run their U product on the side stream (0: none)
+  bool split_build = false;
   int lauum_n[gpc_ctx::MAXG + 1] = {};
 
   // run the device pipeline for samples [s0, s0+cnt) whose matrices start at slot `slot`.
@@ -1630,6 +1657,8 @@ int gpc_create(int device, gpc_ctx** out) {
     ok = hipStreamCreateWithPriority(&c->sst[g], hipStreamNonBlocking, prio_lo) == hipSuccess;
     for (int i = 0; i < gpc_ctx::NDEV && ok; ++i)
       ok = hipEventCreateWithFlags(&c->dev_ev[g][i], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_bfork[g], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&c->ev_btail[g], hipEventDisableTiming) == hipSuccess;
   }
   if (const char* e = getenv("GPC_DEFER_MIN")) c->defer_min = atoi(e);
   if (const char* e = getenv("GPC_DEFER_RESERVE")) c->defer_reserve = atoi(e);
@@ -1677,6 +1706,8 @@ void gpc_destroy(gpc_ctx* c) {
   for (int g = 0; g <= gpc_ctx::MAXG; ++g) {
     for (int i = 0; i < gpc_ctx::NDEV; ++i)
       if (c->dev_ev[g][i]) (void)hipEventDestroy(c->dev_ev[g][i]);
+    if (c->ev_bfork[g]) (void)hipEventDestroy(c->ev_bfork[g]);
+    if (c->ev_btail[g]) (void)hipEventDestroy(c->ev_btail[g]);
     if (c->sst[g]) (void)hipStreamDestroy(c->sst[g]);
   }
   for (int g = 0; g < gpc_ctx::MAXG; ++g) {

@@ -46,6 +46,16 @@ struct Factor {
   hipEvent_t* evs = nullptr;  // pool of events for the fork / join pairs
   int nev = 0, ev_used = 0;
   int defer_min = 0, reserve = 0;
+  // rows >= tail_row0 of A are still being built on the side stream (covfun.h: build_persist_kernel); the first
+  // launch that touches them waits for ev_tail
+  hipEvent_t ev_tail = nullptr;
+  int tail_row0 = 1 << 30;
+  void need_rows(int hi) {
+    if (ev_tail && hi > tail_row0) {
+      chk(hipStreamWaitEvent(st, ev_tail, 0));
+      ev_tail = nullptr;
+    }
+  }
   double flops = 0;      // algorithmic flops issued (tile-exact)
   int launches = 0;
   hipError_t err = hipSuccess;
@@ -89,6 +99,7 @@ struct Factor {
 
   void potrf_inv(int off, int n, bool need_inv, bool keep_L) {
     if (n == TILE) {
+      need_rows(off + TILE);
       hipLaunchKernelGGL((leaf3_kernel<T>), dim3(batch), dim3(256), 0, st, blk(A, off, off), sA, npad,
                          blk(W, off, off), sW, npad, off, logdet, info,
                          std::max(0, std::min(TILE, nvalid - off)));
@@ -100,6 +111,7 @@ struct Factor {
     const int n1 = (q / 2) * TILE, n2 = n - n1;
     const int o1 = off, o2 = off + n1;
     potrf_inv(o1, n1, true, keep_L);
+    need_rows(o2 + n2);
     // 2. T21 = A21 * W11^T
     gemm(blk(Tm, o2, o1), sT, blk(A, o2, o1), sA, blk(W, o1, o1), sW, n2, n1, n1, false, false, 1.0,
          0, KLO_ZERO, KHI_COL, 0);
