@@ -59,24 +59,52 @@ __global__ __launch_bounds__(256) void gemv_sub_kernel(const T* __restrict__ A_a
 // (TRC rows, only rows >= the diagonal tile of column k) of W[b][i][k] * z[b][i];
 // grid = (npad/64, npad/TRC, batch).  Pass 2: out[b][k] = scale[b] * sum_ch part (fixed order).
 constexpr int TRC = 128;  // = TILE, so every padded size is a whole number of chunks
+// Each lane owns VEC adjacent columns (one 16-byte load per row), each wave every fourth row of the chunk,
+// eight loads in flight per lane.   grid = (npad / (64 * VEC), npad / TRC, batch)
 template <typename T>
 __global__ __launch_bounds__(256) void trmv_t_part_kernel(const T* __restrict__ W_all, long long sW, int ldw,
                                                           const double* __restrict__ z_all, int npad,
                                                           double* __restrict__ part_all) {
-  __shared__ double red[4][64];
+  using vec_t = typename MM<T>::vec_t;
+  constexpr int VEC = MM<T>::VEC;
+  __shared__ double red[4][64 * VEC];
   const int b = blockIdx.z, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int k = blockIdx.x * 64 + lane;
+  const int k_raw = (blockIdx.x * 64 + lane) * VEC;
+  const int k = min(k_raw, npad - VEC);  // the last block may hang over the edge (npad is a multiple of 128 only)
   const int nch = npad / TRC;
   const int r0 = blockIdx.y * TRC, r1 = r0 + TRC;
-  const int istart = max(r0, (int)((blockIdx.x * 64) & ~127));
+  const int istart = max(r0, (int)((blockIdx.x * 64 * VEC) & ~127));
   const T* Wb = W_all + (size_t)b * sW;
   const double* z = z_all + (size_t)b * npad;
-  double s = 0.0;
-  for (int i = istart + w; i < r1; i += 4) s += (double)Wb[(size_t)i * ldw + k] * z[i];
-  red[w][lane] = s;
+  // a block spans 64 * VEC columns: with VEC = 4 (fp32) that is two column tiles, and the chunk that holds the
+  // diagonal tile of the first lies ABOVE the diagonal tile of the second (never-written storage): masked per lane
+  const bool lane_ok = k_raw < npad && r0 >= (k & ~127);
+  double s[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) s[e] = 0.0;
+  int i = istart + w;
+  for (; i + 28 < r1; i += 32) {
+    vec_t v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const vec_t*>(Wb + (size_t)(i + 4 * u) * ldw + k);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const double zi = z[i + 4 * u];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) s[e] += lane_ok ? (double)v[u][e] * zi : 0.0;
+    }
+  }
+  for (; i < r1; i += 4) {
+    const vec_t v = *reinterpret_cast<const vec_t*>(Wb + (size_t)i * ldw + k);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s[e] += lane_ok ? (double)v[e] * z[i] : 0.0;
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) red[w][lane * VEC + e] = s[e];
   __syncthreads();
-  if (w == 0)
-    part_all[((size_t)b * nch + blockIdx.y) * npad + k] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+  for (int q = threadIdx.x; q < 64 * VEC; q += 256)
+    if (blockIdx.x * 64 * VEC + q < npad)
+      part_all[((size_t)b * nch + blockIdx.y) * npad + blockIdx.x * 64 * VEC + q] = red[0][q] + red[1][q] + red[2][q] + red[3][q];
 }
 
 // grid = (npad/128, batch), 128 threads; scale[b] = 1/sp[b][sp_off] when sp != nullptr

@@ -559,7 +559,7 @@ struct Pipe {
                        npad, npad, d_quad);
     if (mode != MODE_NLL) {
       double* tpart = c->tpart.as<double>() + (size_t)off * (npad / TRC) * npad;
-      hipLaunchKernelGGL((trmv_t_part_kernel<T>), dim3(npad / 64, npad / TRC, n), dim3(256), 0, st, (const T*)Wc,
+      hipLaunchKernelGGL((trmv_t_part_kernel<T>), dim3((npad + 64 * MM<T>::VEC - 1) / (64 * MM<T>::VEC), npad / TRC, n), dim3(256), 0, st, (const T*)Wc,
                          sM, npad, (const double*)zvec, npad, tpart);
       hipLaunchKernelGGL(trmv_t_sum_kernel, dim3(npad / 128, n), dim3(128), 0, st, (const double*)tpart, npad,
                          (const double*)spb, (int)SP_STRIDE, (int)SP_SL, avec);
@@ -1521,7 +1521,7 @@ int append_impl(gpc_post* po, const double* m_star, const double* sn2_star, doub
                      (const double*)po->alpha.as<double>(), n, npad, d_ka);
   // the padding rows of W are identity rows: l[i >= n] = Ks[i] = 0, harmless in W^T l
   double* tpart = c->tpart.as<double>();
-  hipLaunchKernelGGL((trmv_t_part_kernel<T>), dim3(npad / 64, npad / TRC, S), dim3(256), 0, st,
+  hipLaunchKernelGGL((trmv_t_part_kernel<T>), dim3((npad + 64 * MM<T>::VEC - 1) / (64 * MM<T>::VEC), npad / TRC, S), dim3(256), 0, st,
                      (const T*)po->W.as<T>(), sM, npad, (const double*)lv, npad, tpart);
   hipLaunchKernelGGL(trmv_t_sum_kernel, dim3(npad / 128, S), dim3(128), 0, st, (const double*)tpart, npad,
                      (const double*)nullptr, 0, 0, au);
