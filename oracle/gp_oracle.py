@@ -22,6 +22,7 @@ Reference lines followed (paths relative to the reference checkout):
   gaussian_process.py:2357-2521     GP.__core_computation
   gaussian_process.py:1663-1816     GP.predict
   gaussian_process.py:870-884       GP.update full-recompute loop
+  gaussian_process.py:750-844       GP.update rank-one path (one new point)
 
 Third-party arithmetic the reference delegates to (source not in the reference
 tree): scipy.spatial.distance.{pdist,cdist,squareform}, scipy.linalg.{cholesky,
@@ -558,6 +559,51 @@ def core_extended(model, hyp, X, y, s2, sn2_mult=1, with_scale=False):
     if with_scale:
         return float(nlZ), dnlZ.astype(float), cond, bool(L_chol), gscale
     return float(nlZ), dnlZ.astype(float), cond, bool(L_chol)
+
+
+# --------------------------------------------------------------------------
+# rank-one update (gaussian_process.py:750-844, :866-869)
+# --------------------------------------------------------------------------
+
+
+def rank_one_update(model, posts, X, y, x_new, y_new):
+    """GP.update with ONE new point and no new hyperparameters: every posterior gets a new last
+    row/column (high-noise: of the Cholesky factor; low-noise: of -inv) and an updated alpha; a
+    posterior whose update is numerically unstable (sqrt_arg <= 0, :789-798) is recomputed from
+    scratch on the extended data (:866-869).  Returns (posts, X_ext, y_ext, full_updates)."""
+    kernel, degree = model["kernel"], model.get("degree", 0)
+    d = X.shape[1]
+    cov_N = cov_count(kernel, d)
+    noise_N = noise_count(model["noise"])
+    m_star, v_star = predict(model, posts, X, y, x_new, y_new, add_noise=True, separate_samples=True)
+    full_updates = []
+    for s, p in enumerate(posts):
+        hyp_s = p.hyp
+        sn2 = noise(model["noise"], hyp_s[cov_N: cov_N + noise_N], x_new, y_new, 0)
+        sn2_eff = sn2 * p.sn2_mult
+        K = covariance(kernel, hyp_s[0:cov_N], x_new, degree=degree)
+        Ks = covariance(kernel, hyp_s[0:cov_N], X, x_new, degree=degree)
+        L = p.L
+        if p.L_chol:
+            new_col = sla.solve_triangular(L, Ks, trans=1, check_finite=False)
+            sqrt_arg = sn2_eff**2 + K * sn2_eff - np.dot(new_col.T, new_col)
+            if sqrt_arg <= 0.0:
+                full_updates.append(s)
+                continue
+            alpha_update = sla.solve_triangular(L, new_col, trans=0, check_finite=False) / sn2_eff
+            p.L = np.block([[L, new_col / sn2_eff], [np.zeros((1, L.shape[0])), np.sqrt(sqrt_arg) / sn2_eff]])
+        else:
+            alpha_update = np.dot(-L, Ks)
+            v = -alpha_update / v_star[:, s]
+            p.L = np.block([[L + np.dot(v, alpha_update.T), -v], [-v.T, -1 / v_star[:, s]]])
+        p.sW = np.concatenate((p.sW, np.array([[1 / np.sqrt(sn2_eff)]])))
+        p.alpha = np.concatenate((p.alpha, np.array([[0]]))) + (m_star[:, s] - y_new) / v_star[:, s] * np.concatenate(
+            (alpha_update, np.array([[-1]]))
+        )
+    X2, y2 = np.concatenate((X, x_new)), np.concatenate((y, y_new))
+    for s in full_updates:
+        posts[s] = core(model, posts[s].hyp, X2, y2, None, 0, 0)
+    return posts, X2, y2, full_updates
 
 
 # --------------------------------------------------------------------------

@@ -123,3 +123,29 @@ def test_force_mult_and_extended_precision_restatements(core_golden):
     with pytest.raises(np.linalg.LinAlgError):
         orc.core(model, g[tag + "_hyp"][0], g[tag + "_X"], g[tag + "_y"], None, 1, 1,
                  force_mult=g[tag + "_sn2_mult"][0] / 100)
+
+
+def test_rank_one_update_bit_exact():
+    """The oracle's restatement of the reference's rank-one update path (gaussian_process.py:750-844)
+    against the reference's own results (rank1_cases.npz): three consecutive one-point updates,
+    high- and low-noise parametrisation."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "rank1_cases.npz"), allow_pickle=False)
+    for name in g["names"]:
+        tag, kname, mname, npar, N, D, flav = str(name).split("|")
+        degree, kernel = 0, kname
+        if kname.startswith("matern"):
+            kernel, degree = "matern", int(kname[6:])
+        model = dict(kernel=kernel, degree=degree, mean=mname, noise=tuple(int(c) for c in npar))
+        X, y, hyp, xs = g[tag + "_X"], g[tag + "_y"], g[tag + "_hyp"], g[tag + "_xs"]
+        posts = orc.posteriors(model, hyp, X, y, None)
+        for k in range(3):
+            posts, X, y, full = orc.rank_one_update(model, posts, X, y, g[tag + "_Xn"][k:k + 1], g[tag + "_yn"][k:k + 1])
+            assert full == []
+            mu, s2 = orc.predict(model, posts, X, y, xs, separate_samples=True)
+            assert _eq(mu, g[tag + f"_mu{k}"]) and _eq(s2, g[tag + f"_s2{k}"]), (name, k)
+        for s, p in enumerate(posts):
+            assert _eq(p.alpha[:, 0], g[tag + "_alpha"][s]) and _eq(p.sW[:, 0], g[tag + "_sW"][s]), name
+            assert _eq(np.diag(p.L), g[tag + "_Ldiag"][s]) and _eq(np.asarray(p.L)[:, -1], g[tag + "_Llast_col"][s]), name
+            assert _eq(np.asarray(p.L)[-1, :], g[tag + "_Llast_row"][s]), name
