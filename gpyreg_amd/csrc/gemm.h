@@ -395,8 +395,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(GemmArgs g) {
 // (profiles/r01g_coresidency_probe.txt).
 // XCD affinity (default; GPC_XCD_AFFINE=0 clears g.flags & 8): the (tile, sample) pairs are split into 8 queues by sample index
 // and a block serves the queue of the XCD it runs on first (HW_REG_XCC_ID), stealing from the
-// others when its own is empty.  Blocks that share an L2 then work on tiles of the same one
-// or two samples, consecutive tiles of a sample share an operand panel, and the panel is read
+// others when its own is empty.  Blocks that share an L2 then work on tiles of the same
+// sample, consecutive tiles of a sample share an operand panel, and the panel is read
 // from HBM / Infinity Cache once per XCD instead of once per tile.
 constexpr int NQ = 8;
 template <typename T, bool AKM, bool BKM, int BT, int NW>
@@ -454,7 +454,13 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_persist_kernel(GemmArgs 
       const int idx = __builtin_amdgcn_readfirstlane(next_tile);
       __syncthreads();
       if (idx >= total) break;
-      gemm_tile<T, AKM, BKM, BT, NW>(g, cls + (idx / nsq) * nclass, smp + NQ * (idx % nsq), smem);
+      // sample-major inside a queue: all tiles of the queue's first sample (longest first), then its second,
+      // ... so the 64 blocks of an XCD work on neighbouring tiles of ONE sample and share its operand panels
+      // through their L2.  (Interleaving the samples tile by tile, as round 1 did, put 8 samples' panels
+      // into every XCD's L2 at once: cfg3 W^T W 5.58 -> 5.36 ms, step 20.9 -> 20.4 ms; cfg5 552 -> 531 ms.)
+      const int ntq = total / nsq;
+      const int sq = idx / ntq, tq = idx - sq * ntq;
+      gemm_tile<T, AKM, BKM, BT, NW>(g, cls + tq * nclass, smp + NQ * sq, smem);
     }
   }
 }

@@ -85,7 +85,12 @@ struct Factor {
     flops += gemm_flops(g, batch);
     ++launches;
     int* slot = nullptr;  // NQ counters per persistent launch
-    if (ctr && ctr_used + NQ <= ctr_cap) {
+    // only launches that will run in the persistent form take a slot: a factorization of npad = 8192 or
+    // 16384 has 250-500 launches, and the big ones (which need the slots) come last in the order
+    const long long tm = M / TILE, tn = N / TILE;
+    const long long blocks128 = (lower ? tm * (tm + 1) / 2 : tm * tn) * batch;
+    const bool persistent = rsv || (blocks128 >= g_small_launch_blocks && blocks128 > g_block_slots - g_persist_spare);
+    if (persistent && ctr && ctr_used + NQ <= ctr_cap) {
       slot = ctr + ctr_used;
       ctr_used += NQ;
     }
