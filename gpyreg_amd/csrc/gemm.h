@@ -62,7 +62,7 @@ struct GemmArgs {
   int* ctr = nullptr;  // persistent launches: zeroed device counters the blocks draw tiles from
   int ntiles = 0, batch = 0;
 };
-inline int g_gemm_flags = 8;  // bit 3: XCD-affine tile queues in persistent launches
+inline int g_gemm_flags = 8 | 16;  // bit 3: XCD-affine tile queues in persistent launches; bit 4: XCD-aware order of plain launches
 
 // Staging addresses are split into a block-uniform pointer `u` (tile origin, advanced by the
 // caller one k-slab at a time: scalar adds only) and a per-thread element offset fixed for the
@@ -384,7 +384,22 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
 template <typename T, bool AKM, bool BKM, int BT, int NW>
 __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) T smem[4 * opsz_of<T>(BT)];
-  gemm_tile<T, AKM, BKM, BT, NW>(g, blockIdx.x, blockIdx.y, smem);
+  int bx = blockIdx.x, by = blockIdx.y;
+  if ((g.flags & 16) && gridDim.y >= 8) {
+    // (with fewer than 8 samples a contiguous range is a piece of ONE sample's longest-first tile list: the
+    // XCDs would get unequal work -- cfg4, one sample: -6.5 %)
+    // XCD-aware work order: workgroups are dealt round-robin over the 8 XCDs in dispatch order (x fastest), so
+    // workgroup L runs on XCD L % 8.  Give XCD x the contiguous range [x total/8, (x+1) total/8) of the
+    // (sample, tile) items: its blocks then work on the same one or two samples and share panels in its L2.
+    const int total = gridDim.x * gridDim.y, per = total >> 3;
+    const int L = blockIdx.y * gridDim.x + blockIdx.x;
+    if (L < (per << 3)) {
+      const int wk = (L & 7) * per + (L >> 3);
+      bx = wk % (int)gridDim.x;
+      by = wk / (int)gridDim.x;
+    }
+  }
+  gemm_tile<T, AKM, BKM, BT, NW>(g, bx, by, smem);
 }
 
 // Persistent form for launches with more tiles than block slots: a fixed grid of blocks pulls
