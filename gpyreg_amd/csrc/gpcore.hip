@@ -724,15 +724,15 @@ struct Pipe {
     int groups = c->groups;
     if (cnt < 2 * groups || npad < 1024 || kmode()) groups = 1;
     // Deferred inverse products (plan.h): measured on MI355X (tools/defer_sweep.py) they pay whenever the
-    // latency-bound phases are a visible share of the batch -- S (npad/4096)^3 <= 24 with at least 4 samples:
-    // N=2048 S=16 4.70 -> 4.05 ms, N=4096 S=4 8.46 -> 7.35, N=4096 S=16 21.5 -> 20.8 -- and cost a little
-    // beyond (N=8192 S=64: 556 -> 584 ms).  With them one sample group is better than two.
+    // latency-bound phases are a visible share of the batch -- S (npad/4096)^3 <= 64 with at least 4 samples:
+    // N=2048 S=16 4.42 -> 4.04 ms, N=4096 S=4 8.59 -> 7.47, N=4096 S=16 21.5 -> 20.2, N=4096 S=32 39.4 -> 38.7
+    // -- and cost a little beyond (N=8192 S=64: 556 -> 584 ms).  With them one sample group is better than two.
     defer_node = 0;
     if (mode != MODE_NLL && c->defer_min != 0) {
       const double work = (double)cnt * std::pow((double)npad / 4096.0, 3.0);
       if (c->defer_min > 0)
         defer_node = c->defer_min;
-      else if (cnt >= 4 && npad >= 2048 && work <= 24.0)
+      else if (cnt >= 4 && npad >= 2048 && work <= 64.0)
         defer_node = (npad / 2 / TILE) * TILE;
       if (defer_node > 0) groups = 1;
     }
