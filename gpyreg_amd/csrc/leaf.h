@@ -303,6 +303,305 @@ __global__ __launch_bounds__(256, GPC_LEAF3_WPS) void leaf3_kernel(T* __restrict
   }
 }
 
-inline int g_leaf_version = 3;  // kept for the launch-graph key; one leaf kernel exists
+// ---- leaf5: the same arithmetic as leaf3, software-pipelined over wave-specialised roles --------------
+// leaf3 runs its phases one after the other on all four waves: publish | diag (16 dependent pivots, redundantly
+// in every wave) | solve | update, two block barriers per panel.  The pivot chain is a third of its time and the
+// other two thirds (LDS round trips, barriers, MFMA updates, global stores) sit serially between the chains.
+// Here wave 0 ("diag wave", alone on its SIMD) does nothing but the chain: it factors and inverts A_PP the moment
+// the tile is final, hands W_PP over through LDS and waits for A_(P+1)(P+1).  Waves 1..3 ("update waves") own
+// the 36 accumulator slots (tile rows {7,2,1}, {6,3,0}, {5,4}) and do all the MFMA work of panel P while the diag
+// wave is already inside the chain of panel P+1: the owner of tile row P+1 first computes L_(P+1)P and the one
+// tile the next chain needs (A_(P+1)(P+1) -= L L^T, from its own data, before the panel barrier), signals, and
+// only then joins the rest of the solve and the trailing update.  Hand-offs are LDS flags (release / acquire at
+// workgroup scope); the one hardware barrier per panel separates "L_iP, W_Pj published" from their readers and the
+// diag wave takes part in it at a moment when it has nothing to do.  Images read across that barrier are double
+// buffered by panel parity.  Every tile product is the same MFMA sequence on the same operands as in leaf3, so the
+// results are bit-identical (tests/test_gpu_kernels.py).
+namespace leaf5 {
+constexpr int LDC = 17;   // [row][k] images
+constexpr int LDR = 144;  // [k][col] images
+template <typename T>
+struct Shared {
+  T lcol[2][TILE * LDC];   // L_iP of panel P (parity P & 1), all tile rows
+  T urow[2][16 * LDR];     // W_Pj, j <= P (final row P of the inverse)
+  T colbuf[TILE * LDC];    // A_iP ahead of its solve; rows 16 i .. 16 i + 15 are touched by the owner of row i only
+  T rowbuf[16 * LDR];      // V_Pj, j < P, ahead of the solve of panel P (written in update P-1, read by the owner of row P)
+  T diagA[2][16 * LDC];    // A_PP for the diag wave
+  T diagW[2][16 * LDC];    // W_PP from the diag wave
+  int flagA;               // = P + 1 once A_PP is in diagA[P & 1]
+  int flagW;               // = P + 1 once W_PP is in diagW[P & 1]
+};
+// tile rows of update wave u (0..2), slot r (0..2); -1: none
+__device__ __forceinline__ int tile_row(int u, int r) { return r == 0 ? 7 - u : (r == 1 ? 2 + u : 1 - u); }
+
+// Every wave reaches the end of every wait: a hand-off that never comes (a bug, not a data condition) is reported
+// as a failed pivot after ~0.1 s instead of hanging the queue.
+template <bool SLEEP>
+__device__ __forceinline__ void wait_ge(int* f, int v, int& bad) {
+  int n = 0;
+  while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < v) {
+    if (SLEEP) __builtin_amdgcn_s_sleep(1);
+    if (++n > (1 << 21)) {
+      bad = 1;
+      break;
+    }
+  }
+}
+__device__ __forceinline__ void post(int* f, int v) {
+  __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// block barrier that waits for the wave's LDS traffic only (global stores of L stay in flight)
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// L_iP = A_iP W_PP^T for one owned tile row: colbuf image x wb fragments -> global L, lcol image
+template <typename T>
+__device__ __forceinline__ void solve_tile(const T* __restrict__ colbuf, const T (&wb)[4], T* __restrict__ lc,
+                                           T* __restrict__ Ab, int lda, int i, int P, int lane) {
+  using acc_t = typename MM<T>::acc_t;
+  const int l15 = lane & 15, lq = lane >> 4;
+  acc_t c = acc_t{0, 0, 0, 0};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) c = MM<T>::mma(colbuf[(16 * i + l15) * LDC + 4 * q + lq], wb[q], c);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int row = 16 * i + MM<T>::row_of(lane, e);
+    Ab[(size_t)row * lda + 16 * P + l15] = c[e];
+    lc[row * LDC + l15] = c[e];
+  }
+}
+
+template <typename T, int P>
+__device__ __forceinline__ void update_panel(typename MM<T>::acc_t (&S)[3][8], Shared<T>& sh, T* __restrict__ Ab,
+                                             int lda, int u, int lane, int np, int& bad) {
+  using acc_t = typename MM<T>::acc_t;
+  const int l15 = lane & 15, lq = lane >> 4;
+  T* lc = sh.lcol[P & 1];
+  T* ur = sh.urow[P & 1];
+  const T* dW = sh.diagW[P & 1];
+  wait_ge<true>(&sh.flagW, P + 1, bad);
+  T wb[4];  // B fragments of W_PP^T
+#pragma unroll
+  for (int q = 0; q < 4; ++q) wb[q] = dW[l15 * LDC + 4 * q + lq];
+  // fast path: the owner of tile row P+1 hands the next diagonal tile to the diag wave first
+  if constexpr (P + 1 < 8) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int i = tile_row(u, r);
+      if (i == P + 1 && P + 1 < np) {
+        solve_tile<T>(sh.colbuf, wb, lc, Ab, lda, i, P, lane);
+        __builtin_amdgcn_wave_barrier();
+        T a[4], b[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          b[q] = lc[(16 * i + l15) * LDC + 4 * q + lq];
+          a[q] = -b[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) S[r][P + 1] = MM<T>::mma(a[q], b[q], S[r][P + 1]);
+        T* dA = sh.diagA[(P + 1) & 1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dA[MM<T>::row_of(lane, e) * LDC + l15] = S[r][P + 1][e];
+        post(&sh.flagA, P + 2);
+      }
+    }
+  }
+  // the other owned tile rows below the panel; the owner of row P: final row P of the inverse
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int i = tile_row(u, r);
+    if (i > P + 1 || (i == P + 1 && !(P + 1 < np))) solve_tile<T>(sh.colbuf, wb, lc, Ab, lda, i, P, lane);
+    if (i == P) {
+#pragma unroll
+      for (int j = 0; j < P; ++j) {
+        acc_t c = acc_t{0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          c = MM<T>::mma(dW[l15 * LDC + 4 * q + lq], sh.rowbuf[(4 * q + lq) * LDR + 16 * j + l15], c);
+        S[r][j] = c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ur[MM<T>::row_of(lane, e) * LDR + 16 * j + l15] = c[e];
+      }
+      acc_t c;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        c[e] = dW[MM<T>::row_of(lane, e) * LDC + l15];
+        ur[MM<T>::row_of(lane, e) * LDR + 16 * P + l15] = c[e];
+      }
+      S[r][P] = c;
+    }
+  }
+  lds_barrier();
+  // trailing update of the owned rows below the panel; column P+1 first (it is published for the next solve)
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int i = tile_row(u, r);
+    if (i > P) {
+      T a[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a[q] = -lc[(16 * i + l15) * LDC + 4 * q + lq];
+      S[r][P] = acc_t{0, 0, 0, 0};
+      if constexpr (P + 1 < 8) {
+        if (i > P + 1 || !(P + 1 < np)) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            S[r][P + 1] = MM<T>::mma(a[q], lc[(16 * (P + 1) + l15) * LDC + 4 * q + lq], S[r][P + 1]);
+        }
+        if (i > P + 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sh.colbuf[(16 * i + MM<T>::row_of(lane, e)) * LDC + l15] = S[r][P + 1][e];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (j > i || j == P + 1) continue;
+        if (j > P) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) S[r][j] = MM<T>::mma(a[q], lc[(16 * j + l15) * LDC + 4 * q + lq], S[r][j]);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) S[r][j] = MM<T>::mma(a[q], ur[(4 * q + lq) * LDR + 16 * j + l15], S[r][j]);
+        }
+      }
+      if (i == P + 1) {  // V_(P+1)j, j <= P, is final: image for the solve of panel P+1
+#pragma unroll
+        for (int j = 0; j <= P; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sh.rowbuf[MM<T>::row_of(lane, e) * LDR + 16 * j + l15] = S[r][j][e];
+      }
+    }
+  }
+}
+
+template <typename T, int P>
+__device__ __forceinline__ void diag_panel(Shared<T>& sh, T* __restrict__ Ab, int lda, int lane, double& lg,
+                                           int& bad) {
+  const int l15 = lane & 15, lq = lane >> 4;
+  T d[16], wv[16];
+  if constexpr (P == 0) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) d[c] = Ab[(size_t)l15 * lda + c];
+  } else {
+    wait_ge<false>(&sh.flagA, P + 1, bad);
+    const T* dA = sh.diagA[P & 1];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) d[c] = dA[l15 * LDC + c];
+  }
+  int badk = -1;
+  diag16<T>(d, wv, l15, badk);
+  if (lq == 0) {
+    T* dW = sh.diagW[P & 1];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dW[i * LDC + l15] = wv[i];
+  }
+  post(&sh.flagW, P + 1);
+  if (badk >= 0 && bad == 0) bad = 16 * P + badk + 1;
+  if (lq == 0) {
+    T dkk = d[0];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      if (c <= l15) Ab[(size_t)(16 * P + l15) * lda + 16 * P + c] = d[c];
+      if (c == l15) dkk = d[c];
+    }
+    lg += log((double)dkk);
+  }
+  lds_barrier();
+}
+}  // namespace leaf5
+
+template <typename T>
+__global__ __launch_bounds__(256, 1) void leaf5_kernel(T* __restrict__ A, long long sA, int lda, T* __restrict__ W,
+                                                       long long sW, int ldw, int off, double* __restrict__ logdet,
+                                                       int* __restrict__ info, int nvalid) {
+  using acc_t = typename MM<T>::acc_t;
+  using namespace leaf5;
+  __shared__ Shared<T> sh;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, l15 = lane & 15;
+  T* Ab = A + (size_t)blockIdx.x * sA;
+  T* Wb = W + (size_t)blockIdx.x * sW;
+  // panels that start at or beyond nvalid are identity padding: L = I, W = I, already in place
+  const int np = max(1, min(8, (nvalid + 15) >> 4));
+  if (t == 0) {
+    sh.flagA = 0;
+    sh.flagW = 0;
+  }
+  __syncthreads();
+  int bad = 0;
+  if (w == 0) {
+    double lg = 0.0;
+    diag_panel<T, 0>(sh, Ab, lda, lane, lg, bad);
+    if (np > 1) diag_panel<T, 1>(sh, Ab, lda, lane, lg, bad);
+    if (np > 2) diag_panel<T, 2>(sh, Ab, lda, lane, lg, bad);
+    if (np > 3) diag_panel<T, 3>(sh, Ab, lda, lane, lg, bad);
+    if (np > 4) diag_panel<T, 4>(sh, Ab, lda, lane, lg, bad);
+    if (np > 5) diag_panel<T, 5>(sh, Ab, lda, lane, lg, bad);
+    if (np > 6) diag_panel<T, 6>(sh, Ab, lda, lane, lg, bad);
+    if (np > 7) diag_panel<T, 7>(sh, Ab, lda, lane, lg, bad);
+    lg = wave_sum(lg);
+    if (lane == 0) {
+      if (bad) atomicCAS(info + blockIdx.x, 0, off + bad);
+      atomicAdd(logdet + blockIdx.x, lg);
+    }
+    return;
+  }
+  const int u = w - 1;
+  acc_t S[3][8];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int i = tile_row(u, r);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      S[r][j] = acc_t{0, 0, 0, 0};
+      if (j <= i) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = 16 * i + MM<T>::row_of(lane, e), col = 16 * j + l15;
+          S[r][j][e] = (col <= row) ? Ab[(size_t)row * lda + col] : (T)0;
+        }
+      }
+    }
+    if (i > 0) {  // image of A_i0 for the solve of panel 0
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sh.colbuf[(16 * i + MM<T>::row_of(lane, e)) * LDC + l15] = S[r][0][e];
+    }
+  }
+  update_panel<T, 0>(S, sh, Ab, lda, u, lane, np, bad);
+  if (np > 1) update_panel<T, 1>(S, sh, Ab, lda, u, lane, np, bad);
+  if (np > 2) update_panel<T, 2>(S, sh, Ab, lda, u, lane, np, bad);
+  if (np > 3) update_panel<T, 3>(S, sh, Ab, lda, u, lane, np, bad);
+  if (np > 4) update_panel<T, 4>(S, sh, Ab, lda, u, lane, np, bad);
+  if (np > 5) update_panel<T, 5>(S, sh, Ab, lda, u, lane, np, bad);
+  if (np > 6) update_panel<T, 6>(S, sh, Ab, lda, u, lane, np, bad);
+  if (np > 7) update_panel<T, 7>(S, sh, Ab, lda, u, lane, np, bad);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int i = tile_row(u, r);
+    if (i < 0) continue;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = 16 * i + MM<T>::row_of(lane, e), col = 16 * j + l15;
+        Wb[(size_t)row * ldw + col] = (j <= i) ? S[r][j][e] : (T)0;
+      }
+  }
+  if (bad && lane == 0) atomicCAS(info + blockIdx.x, 0, off + 1);  // a hand-off timed out (never expected)
+}
+
+inline int g_leaf_version = 5;  // 5: pipelined leaf5 (default), 3: the barrier-per-phase leaf3
+
+template <typename T>
+inline void launch_leaf(hipStream_t st, int batch, T* A, long long sA, int lda, T* W, long long sW, int ldw, int off,
+                        double* logdet, int* info, int nvalid) {
+  if (g_leaf_version == 3)
+    hipLaunchKernelGGL((leaf3_kernel<T>), dim3(batch), dim3(256), 0, st, A, sA, lda, W, sW, ldw, off, logdet, info,
+                       nvalid);
+  else
+    hipLaunchKernelGGL((leaf5_kernel<T>), dim3(batch), dim3(256), 0, st, A, sA, lda, W, sW, ldw, off, logdet, info,
+                       nvalid);
+}
 
 }  // namespace gpc

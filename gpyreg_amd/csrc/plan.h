@@ -105,9 +105,8 @@ struct Factor {
   void potrf_inv(int off, int n, bool need_inv, bool keep_L) {
     if (n == TILE) {
       need_rows(off + TILE);
-      hipLaunchKernelGGL((leaf3_kernel<T>), dim3(batch), dim3(256), 0, st, blk(A, off, off), sA, npad,
-                         blk(W, off, off), sW, npad, off, logdet, info,
-                         std::max(0, std::min(TILE, nvalid - off)));
+      launch_leaf<T>(st, batch, blk(A, off, off), sA, npad, blk(W, off, off), sW, npad, off, logdet, info,
+                     std::max(0, std::min(TILE, nvalid - off)));
       flops += (2.0 / 3.0) * TILE * (double)TILE * TILE * batch;
       ++launches;
       return;

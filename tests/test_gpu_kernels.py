@@ -101,6 +101,32 @@ def test_factor_inverse_fp64(ctx, n):
     assert abs(logdet - np.log(np.diag(Lref)).sum()) < 1e-10 * max(1, abs(logdet))
 
 
+@pytest.mark.parametrize("n", [128, 5, 16, 17, 100, 113, 300])
+def test_pipelined_leaf_is_bit_identical_to_the_phase_ordered_leaf(ctx, n):
+    """leaf5 (wave-specialised, software-pipelined) performs the same MFMA sequence on the same operands as
+    leaf3 (one phase after the other): L, W = L^-1, log det and info must agree bit for bit, fp64 and fp32."""
+    from gpyreg_amd import _lib
+
+    rng = np.random.default_rng(1000 + n)
+    A = _spd(n, rng)
+    for dtype in (_lib.F64, _lib.F32):
+        out = {}
+        for leaf in (3, 5):
+            ctx.set_option("leaf", leaf)
+            out[leaf] = ctx.debug_factor(A, want_inv=False, dtype=dtype)
+        ctx.set_option("leaf", 5)
+        (L3, W3, _, ld3, i3), (L5, W5, _, ld5, i5) = out[3], out[5]
+        assert i3 == 0 and i5 == 0
+        assert np.array_equal(L3, L5) and np.array_equal(W3, W5) and ld3 == ld5
+    A[n // 2, n // 2] = -1.0  # the same failed pivot is reported
+    infos = []
+    for leaf in (3, 5):
+        ctx.set_option("leaf", leaf)
+        infos.append(ctx.debug_factor(A, want_inv=False)[-1])
+    ctx.set_option("leaf", 5)
+    assert infos[0] == infos[1] == n // 2 + 1
+
+
 def test_factor_reports_non_pd(ctx):
     A = np.eye(200)
     A[150, 150] = -1.0
