@@ -14,18 +14,35 @@
 
 namespace gpc {
 
-// 1/sqrt(x) to working precision from the hardware estimate plus Newton steps (the
-// pivot's square root and reciprocal sit on the serial critical path of every step)
-__device__ __forceinline__ double fast_rsqrt(double x) {
-  double r = __builtin_amdgcn_rsq(x);
-  r = r * (1.5 - 0.5 * x * r * r);
-  r = r * (1.5 - 0.5 * x * r * r);
-  return r;
-}
-__device__ __forceinline__ float fast_rsqrt(float x) {
-  float r = __builtin_amdgcn_rsqf(x);
-  r = r * (1.5f - 0.5f * x * r * r);
-  return r;
+// 1/sqrt(x) to working precision from the hardware estimate plus Newton steps in residual form
+// (y += y (1/2 - (x/2) y^2): three dependent operations per step).  The pivot's square root and reciprocal sit on
+// the serial critical path of every elimination step; diag16 issues these operations one at a time between the
+// (independent) eliminations of the previous pivot.
+__device__ __forceinline__ double rsq_estimate(double x) { return __builtin_amdgcn_rsq(x); }
+__device__ __forceinline__ float rsq_estimate(float x) { return __builtin_amdgcn_rsqf(x); }
+template <typename T>
+struct RsqSteps {
+  static constexpr int N = std::is_same<T, double>::value ? 6 : 3;  // two Newton steps for fp64, one for fp32
+  T h, y, a, e;
+  __device__ __forceinline__ void start(T x) {
+    y = rsq_estimate(x);
+    h = (T)0.5 * x;
+  }
+  __device__ __forceinline__ void step(int i) {  // i = 0 .. N-1, in order
+    switch (i % 3) {
+      case 0: a = h * y; break;
+      case 1: e = __builtin_fma(-a, y, (T)0.5); break;
+      default: y = __builtin_fma(y, e, y); break;
+    }
+  }
+};
+template <typename T>
+__device__ __forceinline__ T fast_rsqrt(T x) {
+  RsqSteps<T> n;
+  n.start(x);
+#pragma unroll
+  for (int i = 0; i < RsqSteps<T>::N; ++i) n.step(i);
+  return n.y;
 }
 
 // ---- leaf3: MFMA-blocked 128 x 128 Cholesky + inverse ----------------------------------------
@@ -62,24 +79,39 @@ __device__ __forceinline__ float bcast16(float v) {
   asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(N));
   return r;
 }
-// dj -= dk * bcast_J(dk);  wj -= bcast_J(dk) * wk
-template <int J>
+// dj -= dk * bcast_J(dk);  wj -= bcast_J(dk) * wk.  NOP: dk was written by the instruction just before (the
+// VALU-write -> DPP-read hazard needs two wait states); later eliminations of the same pivot read a dk that is long settled.
+template <int J, bool NOP>
 __device__ __forceinline__ void elim16(double& dj, double& wj, double dk, double wk) {
   double t;
-  asm volatile(
-      "s_nop 1\n\tv_mov_b64_dpp %2, %3 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fma_f64 %0, -%3, %2, %0\n\tv_fma_f64 %1, -%2, %4, %1"
-      : "+v"(dj), "+v"(wj), "=&v"(t)
-      : "v"(dk), "v"(wk), "n"(J));
+  if constexpr (NOP)
+    asm volatile(
+        "s_nop 1\n\tv_mov_b64_dpp %2, %3 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fma_f64 %0, -%3, %2, %0\n\tv_fma_f64 %1, -%2, %4, %1"
+        : "+v"(dj), "+v"(wj), "=&v"(t)
+        : "v"(dk), "v"(wk), "n"(J));
+  else
+    asm volatile(
+        "v_mov_b64_dpp %2, %3 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fma_f64 %0, -%3, %2, %0\n\tv_fma_f64 %1, -%2, %4, %1"
+        : "+v"(dj), "+v"(wj), "=&v"(t)
+        : "v"(dk), "v"(wk), "n"(J));
 }
-template <int J>
+template <int J, bool NOP>
 __device__ __forceinline__ void elim16(float& dj, float& wj, float dk, float wk) {
   float t;
-  asm volatile(
-      "s_nop 1\n\tv_mov_b32_dpp %2, %3 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fma_f32 %0, -%3, %2, %0\n\tv_fma_f32 %1, -%2, %4, %1"
-      : "+v"(dj), "+v"(wj), "=&v"(t)
-      : "v"(dk), "v"(wk), "n"(J));
+  if constexpr (NOP)
+    asm volatile(
+        "s_nop 1\n\tv_mov_b32_dpp %2, %3 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fma_f32 %0, -%3, %2, %0\n\tv_fma_f32 %1, -%2, %4, %1"
+        : "+v"(dj), "+v"(wj), "=&v"(t)
+        : "v"(dk), "v"(wk), "n"(J));
+  else
+    asm volatile(
+        "v_mov_b32_dpp %2, %3 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fma_f32 %0, -%3, %2, %0\n\tv_fma_f32 %1, -%2, %4, %1"
+        : "+v"(dj), "+v"(wj), "=&v"(t)
+        : "v"(dk), "v"(wk), "n"(J));
 }
 template <int B, int E, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -98,19 +130,39 @@ __device__ __forceinline__ void diag16(T (&d)[16], T (&wv)[16], int l15, int& ba
   // The forward substitution L W = I (lane c solves column c of W; entries above the diagonal
   // come out as exact zeros) rides on the elimination: the multiplier L_jk broadcast for the
   // Schur update of pivot k is the one W needs, so every broadcast feeds two FMAs.
+  //
+  // Look-ahead on the pivot: row k+1 is eliminated first, its diagonal entry is then final, and the reciprocal
+  // square root of pivot k+1 (one estimate + 3 or 6 dependent operations, ~110 cycles when issued back to back)
+  // is issued one operation at a time BETWEEN the remaining eliminations of pivot k, which do not depend on it.
+  // __builtin_amdgcn_sched_barrier pins the interleave (the elimination blocks are volatile asm and keep their
+  // order by themselves; the Newton operations are ordinary code the scheduler would otherwise group).
 #pragma unroll
   for (int i = 0; i < 16; ++i) wv[i] = (l15 == i) ? (T)1 : (T)0;
+  T s = bcast16<0>(d[0]);
+  if (!(s > (T)0)) badk = 0;
+  T r = fast_rsqrt(s);
   static_for<0, 16>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
-    const T s = bcast16<k>(d[k]);
-    if (!(s > (T)0) && badk < 0) badk = k;
-    const T r = fast_rsqrt(s);
     d[k] = d[k] * r;    // column k of L (lane k: L_kk = s / sqrt(s))
     wv[k] = wv[k] * r;  // W[k][c] = (delta_kc - sum_{m<k} L_km W[m][c]) / L_kk
-    static_for<k + 1, 16>([&](auto jc) {
-      constexpr int j = decltype(jc)::value;
-      elim16<j>(d[j], wv[j], d[k], wv[k]);
-    });
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (k + 1 < 16) {
+      elim16<k + 1, true>(d[k + 1], wv[k + 1], d[k], wv[k]);
+      const T sn = bcast16<k + 1>(d[k + 1]);
+      if (!(sn > (T)0) && badk < 0) badk = k + 1;
+      RsqSteps<T> n;
+      n.start(sn);
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<k + 2, 16>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        elim16<j, false>(d[j], wv[j], d[k], wv[k]);
+        if constexpr (j - (k + 2) < RsqSteps<T>::N) n.step(j - (k + 2));
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      constexpr int done = 16 - (k + 2) < 0 ? 0 : 16 - (k + 2);
+      static_for<(done < RsqSteps<T>::N ? done : RsqSteps<T>::N), RsqSteps<T>::N>([&](auto ic) { n.step(decltype(ic)::value); });
+      r = n.y;
+    }
   });
 }
 
@@ -309,14 +361,26 @@ __global__ __launch_bounds__(256, GPC_LEAF3_WPS) void leaf3_kernel(T* __restrict
 // other two thirds (LDS round trips, barriers, MFMA updates, global stores) sit serially between the chains.
 // Here wave 0 ("diag wave", alone on its SIMD) does nothing but the chain: it factors and inverts A_PP the moment
 // the tile is final, hands W_PP over through LDS and waits for A_(P+1)(P+1).  Waves 1..3 ("update waves") own
-// the 36 accumulator slots (tile rows {7,2,1}, {6,3,0}, {5,4}) and do all the MFMA work of panel P while the diag
-// wave is already inside the chain of panel P+1: the owner of tile row P+1 first computes L_(P+1)P and the one
-// tile the next chain needs (A_(P+1)(P+1) -= L L^T, from its own data, before the panel barrier), signals, and
-// only then joins the rest of the solve and the trailing update.  Hand-offs are LDS flags (release / acquire at
-// workgroup scope); the one hardware barrier per panel separates "L_iP, W_Pj published" from their readers and the
-// diag wave takes part in it at a moment when it has nothing to do.  Images read across that barrier are double
-// buffered by panel parity.  Every tile product is the same MFMA sequence on the same operands as in leaf3, so the
-// results are bit-identical (tests/test_gpu_kernels.py).
+// the 36 accumulator slots (tile rows {7,2,1}, {6,3,0}, {5,4}: compile-time roles, so every tile loop is
+// straight-line code) and do all the MFMA work of panel P while the diag wave is already inside the chain of
+// panel P+1: the owner of tile row P+1 first computes L_(P+1)P and the one tile the next chain needs
+// (A_(P+1)(P+1) -= L L^T, from its own data), signals, and only then joins the rest of the solve and the trailing
+// update.  Hand-offs are LDS flags (release / acquire at workgroup scope); "L_iP, W_Pj published" is separated from
+// their readers by an LDS arrival counter of the three update waves -- the diag wave never waits for anything but
+// its next tile, and no hardware barrier is used after the start.  Images read across that point are double
+// buffered by panel parity.  Tile products of one phase are interleaved over their independent accumulators
+// (k-step outermost); every accumulator still sees the MFMA sequence of leaf3 on the same operands, so the results
+// are bit-identical (tests/test_gpu_kernels.py).
+//
+// tools/leaf_probe.hip defines GPC_LEAF_TRACE: lane 0 of every wave stamps the shader clock at the phase boundaries
+#ifdef GPC_LEAF_TRACE
+__device__ long long* g_leaf_trace = nullptr;  // [4 waves][8 panels][8 stamps]
+#define LEAF_TS(W, P, k) \
+  do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_leaf_trace[((W) * 8 + (P)) * 8 + (k)] = clock64(); } while (0)
+#else
+#define LEAF_TS(W, P, k) do { } while (0)
+#endif
+
 namespace leaf5 {
 constexpr int LDC = 17;   // [row][k] images
 constexpr int LDR = 144;  // [k][col] images
@@ -328,11 +392,17 @@ struct Shared {
   T rowbuf[16 * LDR];      // V_Pj, j < P, ahead of the solve of panel P (written in update P-1, read by the owner of row P)
   T diagA[2][16 * LDC];    // A_PP for the diag wave
   T diagW[2][16 * LDC];    // W_PP from the diag wave
+  T diagL[2][16 * LDC];    // L_PP from the diag wave (its owner among the update waves writes it to memory)
+  T piv[TILE];             // diag L, for the log-determinant
+  double logv[8][16];
   int flagA;               // = P + 1 once A_PP is in diagA[P & 1]
   int flagW;               // = P + 1 once W_PP is in diagW[P & 1]
+  int arrivedL;            // update waves that have published their L_iP of panel P: 3 (P + 1) when all have
+  int arrivedW;            // = P + 1 once the owner of tile row P has published W_Pj, j <= P
 };
-// tile rows of update wave u (0..2), slot r (0..2); -1: none
-__device__ __forceinline__ int tile_row(int u, int r) { return r == 0 ? 7 - u : (r == 1 ? 2 + u : 1 - u); }
+// tile rows of update wave U (0..2), slot r (0..2); -1: none
+constexpr int trow(int U, int r) { return r == 0 ? 7 - U : (r == 1 ? 2 + U : 1 - U); }
+constexpr int slot_of(int U, int i) { return trow(U, 0) == i ? 0 : (trow(U, 1) == i ? 1 : (trow(U, 2) == i ? 2 : -1)); }
 
 // Every wave reaches the end of every wait: a hand-off that never comes (a bug, not a data condition) is reported
 // as a failed pivot after ~0.1 s instead of hanging the queue.
@@ -350,130 +420,215 @@ __device__ __forceinline__ void wait_ge(int* f, int v, int& bad) {
 __device__ __forceinline__ void post(int* f, int v) {
   __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-// block barrier that waits for the wave's LDS traffic only (global stores of L stay in flight)
-__device__ __forceinline__ void lds_barrier() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
 
-// L_iP = A_iP W_PP^T for one owned tile row: colbuf image x wb fragments -> global L, lcol image
-template <typename T>
-__device__ __forceinline__ void solve_tile(const T* __restrict__ colbuf, const T (&wb)[4], T* __restrict__ lc,
-                                           T* __restrict__ Ab, int lda, int i, int P, int lane) {
-  using acc_t = typename MM<T>::acc_t;
-  const int l15 = lane & 15, lq = lane >> 4;
-  acc_t c = acc_t{0, 0, 0, 0};
-#pragma unroll
-  for (int q = 0; q < 4; ++q) c = MM<T>::mma(colbuf[(16 * i + l15) * LDC + 4 * q + lq], wb[q], c);
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int row = 16 * i + MM<T>::row_of(lane, e);
-    Ab[(size_t)row * lda + 16 * P + l15] = c[e];
-    lc[row * LDC + l15] = c[e];
-  }
-}
-
-template <typename T, int P>
+template <typename T, int U, int P>
 __device__ __forceinline__ void update_panel(typename MM<T>::acc_t (&S)[3][8], Shared<T>& sh, T* __restrict__ Ab,
-                                             int lda, int u, int lane, int np, int& bad) {
+                                             int lda, int lane, int& bad) {
   using acc_t = typename MM<T>::acc_t;
   const int l15 = lane & 15, lq = lane >> 4;
   T* lc = sh.lcol[P & 1];
   T* ur = sh.urow[P & 1];
   const T* dW = sh.diagW[P & 1];
-  wait_ge<true>(&sh.flagW, P + 1, bad);
-  T wb[4];  // B fragments of W_PP^T
+  constexpr int RF = P + 1 < 8 ? slot_of(U, P + 1) : -1;  // slot of tile row P+1 (fast path) or -1
+  constexpr int RP = slot_of(U, P);                        // slot of tile row P (final row of the inverse) or -1
+  LEAF_TS(U + 1, P, 0);
+  wait_ge<(RF < 0)>(&sh.flagW, P + 1, bad);  // the wave on the critical path polls without sleeping
+  LEAF_TS(U + 1, P, 1);
+  T wb[4];  // fragments of W_PP: B operand of A_iP W_PP^T and A operand of W_PP V_Pj
 #pragma unroll
   for (int q = 0; q < 4; ++q) wb[q] = dW[l15 * LDC + 4 * q + lq];
-  // fast path: the owner of tile row P+1 hands the next diagonal tile to the diag wave first
-  if constexpr (P + 1 < 8) {
+  // fast path: the owner of tile row P+1 hands the next diagonal tile to the diag wave before anything else
+  if constexpr (RF >= 0) {
+    constexpr int i = P + 1;
+    acc_t c = acc_t{0, 0, 0, 0};
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int i = tile_row(u, r);
-      if (i == P + 1 && P + 1 < np) {
-        solve_tile<T>(sh.colbuf, wb, lc, Ab, lda, i, P, lane);
-        __builtin_amdgcn_wave_barrier();
-        T a[4], b[4];
+    for (int q = 0; q < 4; ++q) c = MM<T>::mma(sh.colbuf[(16 * i + l15) * LDC + 4 * q + lq], wb[q], c);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          b[q] = lc[(16 * i + l15) * LDC + 4 * q + lq];
-          a[q] = -b[q];
-        }
+    for (int e = 0; e < 4; ++e) lc[(16 * i + MM<T>::row_of(lane, e)) * LDC + l15] = c[e];
+    __builtin_amdgcn_wave_barrier();
+    T b[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) S[r][P + 1] = MM<T>::mma(a[q], b[q], S[r][P + 1]);
-        T* dA = sh.diagA[(P + 1) & 1];
+    for (int q = 0; q < 4; ++q) b[q] = lc[(16 * i + l15) * LDC + 4 * q + lq];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dA[MM<T>::row_of(lane, e) * LDC + l15] = S[r][P + 1][e];
-        post(&sh.flagA, P + 2);
-      }
-    }
+    for (int q = 0; q < 4; ++q) S[RF][i] = MM<T>::mma(-b[q], b[q], S[RF][i]);
+    T* dA = sh.diagA[i & 1];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dA[MM<T>::row_of(lane, e) * LDC + l15] = S[RF][i][e];
+    post(&sh.flagA, i + 1);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) Ab[(size_t)(16 * i + MM<T>::row_of(lane, e)) * lda + 16 * P + l15] = c[e];
   }
-  // the other owned tile rows below the panel; the owner of row P: final row P of the inverse
+  LEAF_TS(U + 1, P, 2);
+  // the other owned tile rows below the panel (k-step outermost over the independent tiles)
+  {
+    acc_t c[3];
 #pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    const int i = tile_row(u, r);
-    if (i > P + 1 || (i == P + 1 && !(P + 1 < np))) solve_tile<T>(sh.colbuf, wb, lc, Ab, lda, i, P, lane);
-    if (i == P) {
+    for (int r = 0; r < 3; ++r) c[r] = acc_t{0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      static_for<0, 3>([&](auto rc) {
+        constexpr int r = decltype(rc)::value, i = trow(U, r);
+        if constexpr (i > P && r != RF) c[r] = MM<T>::mma(sh.colbuf[(16 * i + l15) * LDC + 4 * q + lq], wb[q], c[r]);
+      });
+    static_for<0, 3>([&](auto rc) {
+      constexpr int r = decltype(rc)::value, i = trow(U, r);
+      if constexpr (i > P && r != RF) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = 16 * i + MM<T>::row_of(lane, e);
+          lc[row * LDC + l15] = c[r][e];
+          Ab[(size_t)row * lda + 16 * P + l15] = c[r][e];
+        }
+      }
+    });
+  }
+  if (lane == 0) __hip_atomic_fetch_add(&sh.arrivedL, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  // the owner of tile row P: W_Pj = W_PP V_Pj (j < P) and W_PP itself -- the final row P of the inverse; the other
+  // waves meanwhile update their A tiles, which need the L images only
+  if constexpr (RP >= 0) {
+    if constexpr (P > 0) {
+      acc_t c[P];
+#pragma unroll
+      for (int j = 0; j < P; ++j) c[j] = acc_t{0, 0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < P; ++j) c[j] = MM<T>::mma(wb[q], sh.rowbuf[(4 * q + lq) * LDR + 16 * j + l15], c[j]);
 #pragma unroll
       for (int j = 0; j < P; ++j) {
-        acc_t c = acc_t{0, 0, 0, 0};
+        S[RP][j] = c[j];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          c = MM<T>::mma(dW[l15 * LDC + 4 * q + lq], sh.rowbuf[(4 * q + lq) * LDR + 16 * j + l15], c);
-        S[r][j] = c;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ur[MM<T>::row_of(lane, e) * LDR + 16 * j + l15] = c[e];
+        for (int e = 0; e < 4; ++e) ur[MM<T>::row_of(lane, e) * LDR + 16 * j + l15] = c[j][e];
       }
-      acc_t c;
+    }
+    acc_t c;
+    const T* dL = sh.diagL[P & 1];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        c[e] = dW[MM<T>::row_of(lane, e) * LDC + l15];
-        ur[MM<T>::row_of(lane, e) * LDR + 16 * P + l15] = c[e];
-      }
-      S[r][P] = c;
+    for (int e = 0; e < 4; ++e) {
+      const int row = MM<T>::row_of(lane, e);
+      c[e] = dW[row * LDC + l15];
+      ur[row * LDR + 16 * P + l15] = c[e];
+    }
+    S[RP][P] = c;
+    post(&sh.arrivedW, P + 1);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = MM<T>::row_of(lane, e);
+      if (l15 <= row) Ab[(size_t)(16 * P + row) * lda + 16 * P + l15] = dL[row * LDC + l15];
     }
   }
-  lds_barrier();
-  // trailing update of the owned rows below the panel; column P+1 first (it is published for the next solve)
+  LEAF_TS(U + 1, P, 3);
+  if constexpr (trow(U, 0) > P) {
+    // trailing update of the owned rows below the panel, k-step outermost: the B fragment of tile column j is read
+    // once per k-step and serves every owned row.  A tiles (j > P) first: they wait for the L images only.
+    wait_ge<true>(&sh.arrivedL, 3 * (P + 1), bad);
+    LEAF_TS(U + 1, P, 4);
+    T a[3][4];
+    static_for<0, 3>([&](auto rc) {
+      constexpr int r = decltype(rc)::value, i = trow(U, r);
+      if constexpr (i > P) {
 #pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    const int i = tile_row(u, r);
-    if (i > P) {
-      T a[4];
+        for (int q = 0; q < 4; ++q) a[r][q] = -lc[(16 * i + l15) * LDC + 4 * q + lq];
+        S[r][P] = acc_t{0, 0, 0, 0};
+      }
+    });
 #pragma unroll
-      for (int q = 0; q < 4; ++q) a[q] = -lc[(16 * i + l15) * LDC + 4 * q + lq];
-      S[r][P] = acc_t{0, 0, 0, 0};
-      if constexpr (P + 1 < 8) {
-        if (i > P + 1 || !(P + 1 < np)) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            S[r][P + 1] = MM<T>::mma(a[q], lc[(16 * (P + 1) + l15) * LDC + 4 * q + lq], S[r][P + 1]);
+    for (int q = 0; q < 4; ++q)
+      static_for<P + 1, 8>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (j <= trow(U, 0)) {  // row slot 0 is the lowest owned row: the widest
+          const T b = lc[(16 * j + l15) * LDC + 4 * q + lq];
+          static_for<0, 3>([&](auto rc) {
+            constexpr int r = decltype(rc)::value, i = trow(U, r);
+            if constexpr (i > P && j <= i && !(r == RF && j == P + 1)) S[r][j] = MM<T>::mma(a[r][q], b, S[r][j]);
+          });
         }
-        if (i > P + 1) {
+      });
+    if constexpr (P + 1 < 8) {  // images of A_i(P+1) for the solve of the next panel
+      static_for<0, 3>([&](auto rc) {
+        constexpr int r = decltype(rc)::value, i = trow(U, r);
+        if constexpr (i > P + 1) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) sh.colbuf[(16 * i + MM<T>::row_of(lane, e)) * LDC + l15] = S[r][P + 1][e];
         }
-      }
+      });
+    }
+    // V tiles (j <= P) need the final row P of the inverse
+    wait_ge<true>(&sh.arrivedW, P + 1, bad);
+    LEAF_TS(U + 1, P, 5);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if (j > i || j == P + 1) continue;
-        if (j > P) {
+    for (int q = 0; q < 4; ++q)
+      static_for<0, P + 1>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const T b = ur[(4 * q + lq) * LDR + 16 * j + l15];
+        static_for<0, 3>([&](auto rc) {
+          constexpr int r = decltype(rc)::value, i = trow(U, r);
+          if constexpr (i > P) S[r][j] = MM<T>::mma(a[r][q], b, S[r][j]);
+        });
+      });
+    if constexpr (RF >= 0) {  // V_(P+1)j is final: image for the solve of the next panel
 #pragma unroll
-          for (int q = 0; q < 4; ++q) S[r][j] = MM<T>::mma(a[q], lc[(16 * j + l15) * LDC + 4 * q + lq], S[r][j]);
-        } else {
+      for (int j = 0; j <= P; ++j)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) S[r][j] = MM<T>::mma(a[q], ur[(4 * q + lq) * LDR + 16 * j + l15], S[r][j]);
-        }
-      }
-      if (i == P + 1) {  // V_(P+1)j, j <= P, is final: image for the solve of panel P+1
-#pragma unroll
-        for (int j = 0; j <= P; ++j)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) sh.rowbuf[MM<T>::row_of(lane, e) * LDR + 16 * j + l15] = S[r][j][e];
-      }
+        for (int e = 0; e < 4; ++e) sh.rowbuf[MM<T>::row_of(lane, e) * LDR + 16 * j + l15] = S[RF][j][e];
     }
   }
+}
+
+template <typename T, int U>
+__device__ __forceinline__ void update_wave(Shared<T>& sh, T* __restrict__ Ab, int lda, T* __restrict__ Wb, int ldw,
+                                            int lane, int np, int& bad) {
+  using acc_t = typename MM<T>::acc_t;
+  const int l15 = lane & 15;
+  acc_t S[3][8];
+  // column 0 and tile (1,1) first: the solve of panel 0 and the first fast path wait for nothing else
+  static_for<0, 8>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    static_for<0, 3>([&](auto rc) {
+      constexpr int r = decltype(rc)::value, i = trow(U, r);
+      if constexpr (i >= 0) {
+        if constexpr (j <= i) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int row = 16 * i + MM<T>::row_of(lane, e), col = 16 * j + l15;
+            const T v = Ab[(size_t)row * lda + col];
+            S[r][j][e] = (j < i || col <= row) ? v : (T)0;
+          }
+        } else {
+          S[r][j] = acc_t{0, 0, 0, 0};
+        }
+      } else {
+        S[r][j] = acc_t{0, 0, 0, 0};
+      }
+    });
+  });
+  static_for<0, 3>([&](auto rc) {  // image of A_i0 for the solve of panel 0
+    constexpr int r = decltype(rc)::value, i = trow(U, r);
+    if constexpr (i > 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sh.colbuf[(16 * i + MM<T>::row_of(lane, e)) * LDC + l15] = S[r][0][e];
+    }
+  });
+  update_panel<T, U, 0>(S, sh, Ab, lda, lane, bad);
+  if (np > 1) update_panel<T, U, 1>(S, sh, Ab, lda, lane, bad);
+  if (np > 2) update_panel<T, U, 2>(S, sh, Ab, lda, lane, bad);
+  if (np > 3) update_panel<T, U, 3>(S, sh, Ab, lda, lane, bad);
+  if (np > 4) update_panel<T, U, 4>(S, sh, Ab, lda, lane, bad);
+  if (np > 5) update_panel<T, U, 5>(S, sh, Ab, lda, lane, bad);
+  if (np > 6) update_panel<T, U, 6>(S, sh, Ab, lda, lane, bad);
+  if (np > 7) update_panel<T, U, 7>(S, sh, Ab, lda, lane, bad);
+  static_for<0, 3>([&](auto rc) {
+    constexpr int r = decltype(rc)::value, i = trow(U, r);
+    if constexpr (i >= 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = 16 * i + MM<T>::row_of(lane, e), col = 16 * j + l15;
+          Wb[(size_t)row * ldw + col] = (j <= i) ? S[r][j][e] : (T)0;
+        }
+    }
+  });
 }
 
 template <typename T, int P>
@@ -481,6 +636,7 @@ __device__ __forceinline__ void diag_panel(Shared<T>& sh, T* __restrict__ Ab, in
                                            int& bad) {
   const int l15 = lane & 15, lq = lane >> 4;
   T d[16], wv[16];
+  LEAF_TS(0, P, 0);
   if constexpr (P == 0) {
 #pragma unroll
     for (int c = 0; c < 16; ++c) d[c] = Ab[(size_t)l15 * lda + c];
@@ -491,24 +647,30 @@ __device__ __forceinline__ void diag_panel(Shared<T>& sh, T* __restrict__ Ab, in
     for (int c = 0; c < 16; ++c) d[c] = dA[l15 * LDC + c];
   }
   int badk = -1;
+  LEAF_TS(0, P, 1);
   diag16<T>(d, wv, l15, badk);
+  LEAF_TS(0, P, 2);
   if (lq == 0) {
     T* dW = sh.diagW[P & 1];
+    T* dL = sh.diagL[P & 1];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) dW[i * LDC + l15] = wv[i];
+    for (int i = 0; i < 16; ++i) {
+      dW[i * LDC + l15] = wv[i];
+      dL[l15 * LDC + i] = d[i];
+    }
   }
   post(&sh.flagW, P + 1);
+  LEAF_TS(0, P, 3);
+  // off the critical path (the wave now waits for the next tile)
   if (badk >= 0 && bad == 0) bad = 16 * P + badk + 1;
   if (lq == 0) {
     T dkk = d[0];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      if (c <= l15) Ab[(size_t)(16 * P + l15) * lda + 16 * P + c] = d[c];
+    for (int c = 1; c < 16; ++c)
       if (c == l15) dkk = d[c];
-    }
-    lg += log((double)dkk);
+    sh.piv[16 * P + l15] = dkk;
   }
-  lds_barrier();
+  LEAF_TS(0, P, 4);
 }
 }  // namespace leaf5
 
@@ -516,17 +678,18 @@ template <typename T>
 __global__ __launch_bounds__(256, 1) void leaf5_kernel(T* __restrict__ A, long long sA, int lda, T* __restrict__ W,
                                                        long long sW, int ldw, int off, double* __restrict__ logdet,
                                                        int* __restrict__ info, int nvalid) {
-  using acc_t = typename MM<T>::acc_t;
   using namespace leaf5;
   __shared__ Shared<T> sh;
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6, l15 = lane & 15;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   T* Ab = A + (size_t)blockIdx.x * sA;
   T* Wb = W + (size_t)blockIdx.x * sW;
   // panels that start at or beyond nvalid are identity padding: L = I, W = I, already in place
   const int np = max(1, min(8, (nvalid + 15) >> 4));
-  if (t == 0) {
+  if (threadIdx.x == 0) {
     sh.flagA = 0;
     sh.flagW = 0;
+    sh.arrivedL = 0;
+    sh.arrivedW = 0;
   }
   __syncthreads();
   int bad = 0;
@@ -540,6 +703,17 @@ __global__ __launch_bounds__(256, 1) void leaf5_kernel(T* __restrict__ A, long l
     if (np > 5) diag_panel<T, 5>(sh, Ab, lda, lane, lg, bad);
     if (np > 6) diag_panel<T, 6>(sh, Ab, lda, lane, lg, bad);
     if (np > 7) diag_panel<T, 7>(sh, Ab, lda, lane, lg, bad);
+    // sum(log diag L): two logarithms per lane instead of eight in a row, summed per column in panel order
+    // (the order of leaf3) by the first row of 16 lanes
+    __builtin_amdgcn_wave_barrier();
+    {
+      const int l15 = lane & 15, lq = lane >> 4;
+      if (lq < np) sh.logv[lq][l15] = log((double)sh.piv[16 * lq + l15]);
+      if (lq + 4 < np) sh.logv[lq + 4][l15] = log((double)sh.piv[16 * (lq + 4) + l15]);
+      __builtin_amdgcn_wave_barrier();
+      if (lq == 0)
+        for (int P = 0; P < np; ++P) lg += sh.logv[P][l15];
+    }
     lg = wave_sum(lg);
     if (lane == 0) {
       if (bad) atomicCAS(info + blockIdx.x, 0, off + bad);
@@ -547,47 +721,12 @@ __global__ __launch_bounds__(256, 1) void leaf5_kernel(T* __restrict__ A, long l
     }
     return;
   }
-  const int u = w - 1;
-  acc_t S[3][8];
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    const int i = tile_row(u, r);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      S[r][j] = acc_t{0, 0, 0, 0};
-      if (j <= i) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int row = 16 * i + MM<T>::row_of(lane, e), col = 16 * j + l15;
-          S[r][j][e] = (col <= row) ? Ab[(size_t)row * lda + col] : (T)0;
-        }
-      }
-    }
-    if (i > 0) {  // image of A_i0 for the solve of panel 0
-#pragma unroll
-      for (int e = 0; e < 4; ++e) sh.colbuf[(16 * i + MM<T>::row_of(lane, e)) * LDC + l15] = S[r][0][e];
-    }
-  }
-  update_panel<T, 0>(S, sh, Ab, lda, u, lane, np, bad);
-  if (np > 1) update_panel<T, 1>(S, sh, Ab, lda, u, lane, np, bad);
-  if (np > 2) update_panel<T, 2>(S, sh, Ab, lda, u, lane, np, bad);
-  if (np > 3) update_panel<T, 3>(S, sh, Ab, lda, u, lane, np, bad);
-  if (np > 4) update_panel<T, 4>(S, sh, Ab, lda, u, lane, np, bad);
-  if (np > 5) update_panel<T, 5>(S, sh, Ab, lda, u, lane, np, bad);
-  if (np > 6) update_panel<T, 6>(S, sh, Ab, lda, u, lane, np, bad);
-  if (np > 7) update_panel<T, 7>(S, sh, Ab, lda, u, lane, np, bad);
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    const int i = tile_row(u, r);
-    if (i < 0) continue;
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int row = 16 * i + MM<T>::row_of(lane, e), col = 16 * j + l15;
-        Wb[(size_t)row * ldw + col] = (j <= i) ? S[r][j][e] : (T)0;
-      }
-  }
+  if (w == 1)
+    update_wave<T, 0>(sh, Ab, lda, Wb, ldw, lane, np, bad);
+  else if (w == 2)
+    update_wave<T, 1>(sh, Ab, lda, Wb, ldw, lane, np, bad);
+  else
+    update_wave<T, 2>(sh, Ab, lda, Wb, ldw, lane, np, bad);
   if (bad && lane == 0) atomicCAS(info + blockIdx.x, 0, off + 1);  // a hand-off timed out (never expected)
 }
 
