@@ -399,6 +399,7 @@ struct Shared {
   int flagW;               // = P + 1 once W_PP is in diagW[P & 1]
   int arrivedL;            // update waves that have published their L_iP of panel P: 3 (P + 1) when all have
   int arrivedW;            // = P + 1 once the owner of tile row P has published W_Pj, j <= P
+  int rowReady;            // = 1 once V_7j, j < 7, is in rowbuf (the last panel's products are dealt to all three waves)
 };
 // tile rows of update wave U (0..2), slot r (0..2); -1: none
 constexpr int trow(int U, int r) { return r == 0 ? 7 - U : (r == 1 ? 2 + U : 1 - U); }
@@ -423,7 +424,7 @@ __device__ __forceinline__ void post(int* f, int v) {
 
 template <typename T, int U, int P>
 __device__ __forceinline__ void update_panel(typename MM<T>::acc_t (&S)[3][8], Shared<T>& sh, T* __restrict__ Ab,
-                                             int lda, int lane, int& bad) {
+                                             int lda, T* __restrict__ Wb, int ldw, int lane, int& bad) {
   using acc_t = typename MM<T>::acc_t;
   const int l15 = lane & 15, lq = lane >> 4;
   T* lc = sh.lcol[P & 1];
@@ -432,7 +433,7 @@ __device__ __forceinline__ void update_panel(typename MM<T>::acc_t (&S)[3][8], S
   constexpr int RF = P + 1 < 8 ? slot_of(U, P + 1) : -1;  // slot of tile row P+1 (fast path) or -1
   constexpr int RP = slot_of(U, P);                        // slot of tile row P (final row of the inverse) or -1
   LEAF_TS(U + 1, P, 0);
-  wait_ge<(RF < 0)>(&sh.flagW, P + 1, bad);  // the wave on the critical path polls without sleeping
+  wait_ge<(RF < 0 && P < 7)>(&sh.flagW, P + 1, bad);  // the waves on the critical path poll without sleeping
   LEAF_TS(U + 1, P, 1);
   T wb[4];  // fragments of W_PP: B operand of A_iP W_PP^T and A operand of W_PP V_Pj
 #pragma unroll
@@ -485,17 +486,36 @@ __device__ __forceinline__ void update_panel(typename MM<T>::acc_t (&S)[3][8], S
   if (lane == 0) __hip_atomic_fetch_add(&sh.arrivedL, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   // the owner of tile row P: W_Pj = W_PP V_Pj (j < P) and W_PP itself -- the final row P of the inverse; the other
   // waves meanwhile update their A tiles, which need the L images only
-  if constexpr (RP >= 0) {
-    if constexpr (P > 0) {
-      acc_t c[P];
+  // Last panel: nothing is left to update, the chain has ended, and the seven products W_7j are all that stands
+  // between it and the end of the kernel -- the two waves without rows take four of them and store their tiles
+  // of the inverse themselves (LAST_SHARE columns stay with the owner).
+  constexpr int LAST_SHARE = 3;
+  if constexpr (P == 7 && RP < 0) {
+    wait_ge<false>(&sh.rowReady, 1, bad);
+    constexpr int J0 = LAST_SHARE + 2 * (U - 1);
+    acc_t c[2];
+    c[0] = c[1] = acc_t{0, 0, 0, 0};
 #pragma unroll
-      for (int j = 0; j < P; ++j) c[j] = acc_t{0, 0, 0, 0};
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) c[j] = MM<T>::mma(wb[q], sh.rowbuf[(4 * q + lq) * LDR + 16 * (J0 + j) + l15], c[j]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Wb[(size_t)(16 * 7 + MM<T>::row_of(lane, e)) * ldw + 16 * (J0 + j) + l15] = c[j][e];
+  }
+  if constexpr (RP >= 0) {
+    constexpr int NJ = P == 7 ? LAST_SHARE : P;  // tile columns j < NJ of row P are this wave's
+    if constexpr (P > 0) {
+      acc_t c[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) c[j] = acc_t{0, 0, 0, 0};
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int j = 0; j < P; ++j) c[j] = MM<T>::mma(wb[q], sh.rowbuf[(4 * q + lq) * LDR + 16 * j + l15], c[j]);
+        for (int j = 0; j < NJ; ++j) c[j] = MM<T>::mma(wb[q], sh.rowbuf[(4 * q + lq) * LDR + 16 * j + l15], c[j]);
 #pragma unroll
-      for (int j = 0; j < P; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         S[RP][j] = c[j];
 #pragma unroll
         for (int e = 0; e < 4; ++e) ur[MM<T>::row_of(lane, e) * LDR + 16 * j + l15] = c[j][e];
@@ -571,6 +591,7 @@ __device__ __forceinline__ void update_panel(typename MM<T>::acc_t (&S)[3][8], S
       for (int j = 0; j <= P; ++j)
 #pragma unroll
         for (int e = 0; e < 4; ++e) sh.rowbuf[MM<T>::row_of(lane, e) * LDR + 16 * j + l15] = S[RF][j][e];
+      if constexpr (P == 6) post(&sh.rowReady, 1);
     }
   }
 }
@@ -609,24 +630,26 @@ __device__ __forceinline__ void update_wave(Shared<T>& sh, T* __restrict__ Ab, i
       for (int e = 0; e < 4; ++e) sh.colbuf[(16 * i + MM<T>::row_of(lane, e)) * LDC + l15] = S[r][0][e];
     }
   });
-  update_panel<T, U, 0>(S, sh, Ab, lda, lane, bad);
-  if (np > 1) update_panel<T, U, 1>(S, sh, Ab, lda, lane, bad);
-  if (np > 2) update_panel<T, U, 2>(S, sh, Ab, lda, lane, bad);
-  if (np > 3) update_panel<T, U, 3>(S, sh, Ab, lda, lane, bad);
-  if (np > 4) update_panel<T, U, 4>(S, sh, Ab, lda, lane, bad);
-  if (np > 5) update_panel<T, U, 5>(S, sh, Ab, lda, lane, bad);
-  if (np > 6) update_panel<T, U, 6>(S, sh, Ab, lda, lane, bad);
-  if (np > 7) update_panel<T, U, 7>(S, sh, Ab, lda, lane, bad);
+  update_panel<T, U, 0>(S, sh, Ab, lda, Wb, ldw, lane, bad);
+  if (np > 1) update_panel<T, U, 1>(S, sh, Ab, lda, Wb, ldw, lane, bad);
+  if (np > 2) update_panel<T, U, 2>(S, sh, Ab, lda, Wb, ldw, lane, bad);
+  if (np > 3) update_panel<T, U, 3>(S, sh, Ab, lda, Wb, ldw, lane, bad);
+  if (np > 4) update_panel<T, U, 4>(S, sh, Ab, lda, Wb, ldw, lane, bad);
+  if (np > 5) update_panel<T, U, 5>(S, sh, Ab, lda, Wb, ldw, lane, bad);
+  if (np > 6) update_panel<T, U, 6>(S, sh, Ab, lda, Wb, ldw, lane, bad);
+  if (np > 7) update_panel<T, U, 7>(S, sh, Ab, lda, Wb, ldw, lane, bad);
   static_for<0, 3>([&](auto rc) {
     constexpr int r = decltype(rc)::value, i = trow(U, r);
     if constexpr (i >= 0) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
+      for (int j = 0; j < 8; ++j) {
+        if (i == 7 && j >= 3 && j < 7 && np == 8) continue;  // stored by the waves that computed them (last panel)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int row = 16 * i + MM<T>::row_of(lane, e), col = 16 * j + l15;
           Wb[(size_t)row * ldw + col] = (j <= i) ? S[r][j][e] : (T)0;
         }
+      }
     }
   });
 }
@@ -690,6 +713,7 @@ __global__ __launch_bounds__(256, 1) void leaf5_kernel(T* __restrict__ A, long l
     sh.flagW = 0;
     sh.arrivedL = 0;
     sh.arrivedW = 0;
+    sh.rowReady = 0;
   }
   __syncthreads();
   int bad = 0;

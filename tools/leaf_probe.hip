@@ -1,6 +1,7 @@
 // leaf_probe.hip -- where the time of one 128 x 128 leaf goes: per-panel shader-clock stamps of the diag wave and
 // the update waves (leaf5), plus launch-to-launch durations of leaf3 / leaf5 for 1 and 16 blocks.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DGPC_LEAF_TRACE -I gpyreg_amd/csrc -o tools/leaf_probe tools/leaf_probe.hip
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DGPC_LEAF_TRACE] -I gpyreg_amd/csrc -o tools/leaf_probe tools/leaf_probe.hip
+// (without the macro: durations only, of the kernel exactly as the library runs it)
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
@@ -8,7 +9,10 @@
 #include "leaf.h"
 using namespace gpc;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+#ifdef GPC_LEAF_TRACE
 __global__ void set_trace(long long* p) { g_leaf_trace = p; }
+#endif
+__global__ void empty_kernel() {}
 int main() {
   const int n = TILE, B = 16;
   std::vector<double> A((size_t)n * n);
@@ -27,10 +31,26 @@ int main() {
   CK(hipMemset(dlog, 0, sizeof(double) * B));
   CK(hipMemset(dinfo, 0, sizeof(int) * B));
   CK(hipMemset(dtr, 0, sizeof(long long) * 256));
+#ifdef GPC_LEAF_TRACE
   hipLaunchKernelGGL(set_trace, dim3(1), dim3(1), 0, 0, dtr);
+#endif
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
+  {
+    float best = 1e9;
+    for (int rep = 0; rep < 20; ++rep) {
+      CK(hipDeviceSynchronize());
+      CK(hipEventRecord(e0, 0));
+      hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(256), 0, 0);
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      best = std::min(best, ms);
+    }
+    printf("empty kernel: %.1f us (event to event: subtract from the figures below)\n", best * 1e3);
+  }
   for (int ver : {3, 5})
     for (int blocks : {1, 16}) {
       float best = 1e9;
@@ -53,6 +73,9 @@ int main() {
   int info[B];
   CK(hipMemcpy(info, dinfo, sizeof(info), hipMemcpyDeviceToHost));
   printf("info[0]=%d\n", info[0]);
+#ifndef GPC_LEAF_TRACE
+  return 0;
+#endif
   long long tr[4][8][8];
   CK(hipMemcpy(tr, dtr, sizeof(tr), hipMemcpyDeviceToHost));
   const long long t0 = tr[0][0][0];
