@@ -402,6 +402,28 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(GemmArgs g) {
   gemm_tile<T, AKM, BKM, BT, NW>(g, bx, by, smem);
 }
 
+// Two independent products in ONE launch (plan.h: the syrk A22 -= T21 T21^T and the inverse product U = T21 W11 of
+// a node both wait for T21 only): workgroups [0, n1) of a sample are tiles of g1, the rest tiles of g2.  The deep
+// levels of the recursion are bound by the ~5 us every dependent launch costs, not by their flops.
+template <typename T, bool A1, bool B1, bool A2, bool B2, int BT, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 2) void gemm_dual_kernel(GemmArgs g1, GemmArgs g2, int n1) {
+  __shared__ __attribute__((aligned(16))) T smem[4 * opsz_of<T>(BT)];
+  int bx = blockIdx.x, by = blockIdx.y;
+  if ((g1.flags & 16) && gridDim.y >= 8) {  // XCD-aware work order, as in gemm_kernel
+    const int total = gridDim.x * gridDim.y, per = total >> 3;
+    const int L = blockIdx.y * gridDim.x + blockIdx.x;
+    if (L < (per << 3)) {
+      const int wk = (L & 7) * per + (L >> 3);
+      bx = wk % (int)gridDim.x;
+      by = wk / (int)gridDim.x;
+    }
+  }
+  if (bx < n1)
+    gemm_tile<T, A1, B1, BT, NW>(g1, bx, by, smem);
+  else
+    gemm_tile<T, A2, B2, BT, NW>(g2, bx - n1, by, smem);
+}
+
 // Persistent form for launches with more tiles than block slots: a fixed grid of blocks pulls
 // (tile, sample) pairs off a device counter (longest tiles of every sample first).  The grid is
 // `g_persist_spare` blocks short of two per CU, which leaves that many CUs with one resident
@@ -525,6 +547,7 @@ inline hipError_t launch_gemm_bt(hipStream_t st, GemmArgs g, bool akm, bool bkm,
 // a quarter of the work each): the deep levels of the recursion are latency-, not
 // throughput-bound.  force_bt: 0 = choose, 64 / 128 = as given (tests).
 inline int g_small_launch_blocks = 1100;  // tunable: GPC_SMALL_BLOCKS
+inline bool g_dual_launch = true;         // tunable: GPC_DUAL (plan.h: syrk + U of a node in one launch)
 template <typename T>
 inline hipError_t launch_gemm(hipStream_t st, GemmArgs g, bool akm, bool bkm, int batch, int force_bt = 0,
                              int* ctr = nullptr, int reserve = 0) {
@@ -533,6 +556,33 @@ inline hipError_t launch_gemm(hipStream_t st, GemmArgs g, bool akm, bool bkm, in
   const bool small = force_bt ? (force_bt == 64) : (blocks128 < g_small_launch_blocks);
   if (small && !(reserve && ctr)) return launch_gemm_bt<T, 64, 4>(st, g, akm, bkm, batch);
   return launch_gemm_bt<T, 128, 4>(st, g, akm, bkm, batch, ctr, ctr ? reserve : 0);
+}
+
+// true when launch_gemm would run g as a plain 64-tile launch (the precondition of the dual launch)
+inline bool gemm_is_small(const GemmArgs& g, int batch) {
+  const int tm = g.M / TILE, tn = g.N / TILE;
+  return (long long)(g.lower_only ? tm * (tm + 1) / 2 : tm * tn) * batch < g_small_launch_blocks;
+}
+// g1: m-major x m-major (syrk), g2: m-major x k-major (U = T21 W11), both as 64-tile launches in one grid
+template <typename T>
+inline hipError_t launch_gemm_dual_small(hipStream_t st, GemmArgs g1, GemmArgs g2, int batch) {
+  constexpr int BT = 64;
+  int n[2];
+  GemmArgs* gs[2] = {&g1, &g2};
+  for (int i = 0; i < 2; ++i) {
+    GemmArgs& g = *gs[i];
+    g.tiles_m = g.M / BT;
+    g.tiles_n = g.N / BT;
+    g.flags = g_gemm_flags;
+    g.ntiles = n[i] = g.lower_only ? g.tiles_m * (g.tiles_m + 1) / 2 : g.tiles_m * g.tiles_n;
+    g.batch = batch;
+    g.ctr = nullptr;
+    g.reserve = 0;
+  }
+  if (n[0] + n[1] <= 0 || batch <= 0) return hipSuccess;
+  hipLaunchKernelGGL((gemm_dual_kernel<T, false, false, false, true, BT, 4>), dim3(n[0] + n[1], batch), dim3(256), 0, st,
+                     g1, g2, n[0]);
+  return hipGetLastError();
 }
 
 // algorithmic flops of one launch (for the roofline bookkeeping)

@@ -1678,6 +1678,7 @@ int gpc_create(int device, gpc_ctx** out) {
   if (const char* e = getenv("GPC_GRAPH_MAX_NPAD")) c->graph_max_npad = atoi(e);
   if (const char* e = getenv("GPC_GROUPS")) c->groups = std::max(1, std::min((int)gpc_ctx::MAXG, atoi(e)));
   if (const char* e = getenv("GPC_SMALL_BLOCKS")) gpc::g_small_launch_blocks = atoi(e);
+  if (const char* e = getenv("GPC_DUAL")) gpc::g_dual_launch = atoi(e) != 0;
   if (const char* e = getenv("GPC_GEMM_FLAGS")) gpc::g_gemm_flags = atoi(e);
   if (const char* e = getenv("GPC_XCD_AFFINE")) gpc::g_gemm_flags = atoi(e) ? (gpc::g_gemm_flags | 8) : (gpc::g_gemm_flags & ~8);
   *out = c;
@@ -2087,6 +2088,8 @@ int gpc_set_option(gpc_ctx* c, const char* name, int value) {
     c->groups = std::max(1, std::min((int)gpc_ctx::MAXG, value));
   else if (n == "small_blocks")
     gpc::g_small_launch_blocks = value;
+  else if (n == "dual_launch")  // syrk + inverse product of a node in one launch (default 1)
+    gpc::g_dual_launch = value != 0;
   else if (n == "leaf")  // 5: pipelined leaf (default), 3: barrier-per-phase leaf (A/B and bit-identity tests)
     gpc::g_leaf_version = value == 3 ? 3 : 5;
   else if (n == "defer_min")  // deferred inverse products: node size from which U runs on the side stream (0 off, -1 auto)

@@ -254,3 +254,30 @@ def test_deferred_inverse_products_do_not_change_a_bit():
     finally:
         bench.CONFIGS[3] = bench_cfg
         ctx.set_option("defer_min", -1)
+
+
+def test_dual_launches_do_not_change_a_bit():
+    """plan.h launches the syrk A22 -= T21 T21^T and the inverse product U = T21 W11 of a node as ONE grid where
+    both are small launches: a launch less per node, the same arithmetic.  NLL, gradient and posteriors with the
+    dual launches off and on must be identical bit for bit (N = 700 and 2304, S = 1 and 6)."""
+    import bench
+    from gpyreg_amd import _lib
+
+    ctx = _lib.context(0)
+    bench_cfg = dict(bench.CONFIGS[3])
+    try:
+        for N, S in ((700, 1), (2304, 6)):
+            bench.CONFIGS[3] = dict(bench_cfg, N=N)
+            X, y, hyp = bench.synthetic_problem(3, S)
+            xs = X[:33] + 0.01
+            res = []
+            for dual in (0, 1):
+                ctx.set_option("dual_launch", dual)
+                gp = bench.make_gp(3, "f64")
+                gp.update(X_new=X, y_new=y, hyp=hyp)
+                res.append(gp.nll_batch(hyp, compute_grad=True) + gp.predict(xs, separate_samples=True))
+            for a, b in zip(res[0], res[1]):
+                assert np.array_equal(a, b)
+    finally:
+        bench.CONFIGS[3] = bench_cfg
+        ctx.set_option("dual_launch", 1)
