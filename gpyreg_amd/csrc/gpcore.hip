@@ -64,6 +64,35 @@ struct DevBuf {
 // memcpy (~30 GB/s) and makes the copy truly asynchronous.  Lifetime: begin() at the top of an
 // entry point (the stream is idle there: every entry point ends with a sync), finish() after
 // the final sync delivers the downloads.
+// Gathered transfers of one call.  The boundary hands over 5-7 small host arrays per call (hyperparameter rows, mean,
+// noise, their gradients' inputs) and takes back 3-6 (log det, quadratic form, info, gradients): as separate
+// hipMemcpyAsync's each is a blit kernel of its own on the stream (~10 us apiece, 100-190 us per call against
+// 250 us of device work for a single evaluation at N = 200).  Here the host side stages everything in ONE pinned
+// block and one kernel moves the segments (the pinned block is mapped: the kernel reads / writes host memory over
+// the bus directly) and zeroes the scalar block on the way.
+struct XferSeg {
+  void* dst;
+  const void* src;
+  unsigned long long n8;  // 8-byte words
+};
+struct XferDesc {
+  static constexpr int MAXSEG = 8;
+  XferSeg seg[MAXSEG];
+  int nseg;
+  void* zero;
+  unsigned long long zero8;
+};
+__global__ __launch_bounds__(256) void xfer_kernel(XferDesc d) {
+  const unsigned long long gt = (unsigned long long)blockIdx.x * 256 + threadIdx.x, stride = (unsigned long long)gridDim.x * 256;
+  for (int k = 0; k < d.nseg; ++k) {
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(d.seg[k].dst);
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(d.seg[k].src);
+    for (unsigned long long i = gt; i < d.seg[k].n8; i += stride) dst[i] = src[i];
+  }
+  unsigned long long* z = reinterpret_cast<unsigned long long*>(d.zero);
+  for (unsigned long long i = gt; i < d.zero8; i += stride) z[i] = 0ull;
+}
+
 struct PinBuf {
   struct Blk {
     char* p;
@@ -128,6 +157,70 @@ struct PinBuf {
   void finish() {
     for (Pending& q : pend) memcpy(q.dst, q.src, q.n);
     pend.clear();
+  }
+  // ---- gathered form: stage() any number of uploads (<= MAXSEG), flush_up() moves them with one kernel;
+  // gather() downloads likewise, flush_down() + (after the stream is synchronised) finish().
+  // Falls back to individual copies when a segment is not 8-byte sized, the total is large enough for the copy
+  // engines to win (kGather), or pinned memory is not to be had.
+  static constexpr size_t kGather = 2u << 20;
+  XferDesc upd{}, downd{};
+  std::vector<Pending> up_fallback;
+  void begin_gather() {
+    upd.nseg = downd.nseg = 0;
+    upd.zero = downd.zero = nullptr;
+    upd.zero8 = downd.zero8 = 0;
+    up_fallback.clear();
+    gathered_bytes = 0;
+  }
+  size_t gathered_bytes = 0;
+  void stage(void* dst, const void* src, size_t n) {
+    if (n == 0) return;
+    void* h = (n % 8 == 0 && upd.nseg < XferDesc::MAXSEG && gathered_bytes + n <= kGather) ? alloc(n) : nullptr;
+    if (!h) {
+      up_fallback.push_back({dst, src, n});
+      return;
+    }
+    memcpy(h, src, n);
+    upd.seg[upd.nseg++] = {dst, h, (unsigned long long)(n / 8)};
+    gathered_bytes += n;
+  }
+  hipError_t flush_up(hipStream_t st, void* zero, size_t zero_bytes) {
+    for (Pending& q : up_fallback) {
+      hipError_t e = up(q.dst, q.src, q.n, st);
+      if (e != hipSuccess) return e;
+    }
+    up_fallback.clear();
+    if (zero_bytes % 8) {
+      hipError_t e = hipMemsetAsync(zero, 0, zero_bytes, st);
+      if (e != hipSuccess) return e;
+      zero_bytes = 0;
+    }
+    upd.zero = zero;
+    upd.zero8 = zero_bytes / 8;
+    if (upd.nseg == 0 && upd.zero8 == 0) return hipSuccess;
+    const unsigned long long words = gathered_bytes / 8 + upd.zero8;
+    const int blocks = (int)std::min<unsigned long long>(256, (words + 255) / 256);
+    hipLaunchKernelGGL(xfer_kernel, dim3(std::max(1, blocks)), dim3(256), 0, st, upd);
+    upd.nseg = 0;
+    return hipGetLastError();
+  }
+  // dst: host; the data lands there at finish()
+  hipError_t gather(void* dst, const void* src, size_t n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    void* h = (n % 8 == 0 && downd.nseg < XferDesc::MAXSEG && n <= kGather / 8) ? alloc(n) : nullptr;
+    if (!h) return hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, st);
+    pend.push_back({dst, h, n});
+    downd.seg[downd.nseg++] = {h, src, (unsigned long long)(n / 8)};
+    return hipSuccess;
+  }
+  hipError_t flush_down(hipStream_t st) {
+    if (downd.nseg == 0) return hipSuccess;
+    unsigned long long words = 0;
+    for (int k = 0; k < downd.nseg; ++k) words += downd.seg[k].n8;
+    const int blocks = (int)std::min<unsigned long long>(64, (words + 255) / 256);
+    hipLaunchKernelGGL(xfer_kernel, dim3(std::max(1, blocks)), dim3(256), 0, st, downd);
+    downd.nseg = 0;
+    return hipGetLastError();
   }
   void release() {
     for (Blk& b : blks) (void)hipHostFree(b.p);
@@ -707,18 +800,19 @@ struct Pipe {
 
     HostClock hc("run");
     c->pin.begin();
-    auto up = [&](void* dst, const void* src, size_t n) { return c->pin.up(dst, src, n, st); };
+    c->pin.begin_gather();
+    auto up = [&](void* dst, const void* src, size_t n) { c->pin.stage(dst, src, n); };
     HIPCHK(c, hipEventRecord(c->ev[0], st));
-    HIPCHK(c, up(c->spb.p, &b.sp[(size_t)s0 * SP_STRIDE], (size_t)cnt * SP_STRIDE * 8));
-    HIPCHK(c, up(c->mulb.p, &b.mul[(size_t)s0 * D], (size_t)cnt * D * 8));
-    HIPCHK(c, up(c->divb.p, &b.dv[(size_t)s0 * D], (size_t)cnt * D * 8));
-    HIPCHK(c, up(c->dvec.p, &b.dvec[(size_t)s0 * npad], cnt * vb));
-    HIPCHK(c, up(c->rvec.p, &b.r[(size_t)s0 * npad], cnt * vb));
-    HIPCHK(c, hipMemsetAsync(c->scal.p, 0, (size_t)cnt * (2 * sizeof(double) + sizeof(int)), st));
-    if (mode == MODE_GRAD && mean_N > 0)
-      HIPCHK(c, up(c->dmb.p, dm + (size_t)s0 * N * mean_N, (size_t)cnt * N * mean_N * 8));
+    up(c->spb.p, &b.sp[(size_t)s0 * SP_STRIDE], (size_t)cnt * SP_STRIDE * 8);
+    up(c->mulb.p, &b.mul[(size_t)s0 * D], (size_t)cnt * D * 8);
+    up(c->divb.p, &b.dv[(size_t)s0 * D], (size_t)cnt * D * 8);
+    up(c->dvec.p, &b.dvec[(size_t)s0 * npad], cnt * vb);
+    up(c->rvec.p, &b.r[(size_t)s0 * npad], cnt * vb);
+    if (mode == MODE_GRAD && mean_N > 0) up(c->dmb.p, dm + (size_t)s0 * N * mean_N, (size_t)cnt * N * mean_N * 8);
     if (mode == MODE_GRAD && noise_N > 0 && b.vec_noise)
-      HIPCHK(c, up(c->dsn2b.p, dsn2 + (size_t)s0 * N * noise_N, (size_t)cnt * N * noise_N * 8));
+      up(c->dsn2b.p, dsn2 + (size_t)s0 * N * noise_N, (size_t)cnt * N * noise_N * 8);
+    // one kernel: every staged segment and the zeroing of [logdet | quad | info] (padded to whole words)
+    HIPCHK(c, c->pin.flush_up(st, c->scal.p, (((size_t)cnt * (2 * sizeof(double) + sizeof(int))) + 7) & ~(size_t)7));
 
     hc.lap("h2d");
     int groups = c->groups;
@@ -763,20 +857,23 @@ struct Pipe {
 
     hc.lap("launch");
     // results back
-    std::vector<int> hinfo(cnt);
-    HIPCHK(c, hipMemcpyAsync(&logdet[s0], d_logdet, cnt * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(&quad[s0], d_quad, cnt * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(hinfo.data(), d_info, cnt * sizeof(int), hipMemcpyDeviceToHost, st));
+    std::vector<int> hinfo((cnt + 1) & ~1);
+    // [logdet | quad | info] are contiguous on the device: one segment (info padded to a whole word)
+    const size_t scal_bytes = (((size_t)cnt * (2 * sizeof(double) + sizeof(int))) + 7) & ~(size_t)7;
+    std::vector<double> hscal(scal_bytes / 8);
+    HIPCHK(c, c->pin.gather(hscal.data(), d_logdet, scal_bytes, st));
     if (mode == MODE_GRAD) {
-      HIPCHK(c, hipMemcpyAsync(&G[(size_t)s0 * Pn], c->gout.p, (size_t)cnt * Pn * 8, hipMemcpyDeviceToHost, st));
-      if (mean_N > 0)
-        HIPCHK(c, hipMemcpyAsync(&mg[(size_t)s0 * mean_N], c->mg.p, (size_t)cnt * mean_N * 8,
-                                 hipMemcpyDeviceToHost, st));
+      HIPCHK(c, c->pin.gather(&G[(size_t)s0 * Pn], c->gout.p, (size_t)cnt * Pn * 8, st));
+      if (mean_N > 0) HIPCHK(c, c->pin.gather(&mg[(size_t)s0 * mean_N], c->mg.p, (size_t)cnt * mean_N * 8, st));
       if (noise_N > 0 && b.vec_noise)
-        HIPCHK(c, hipMemcpyAsync(&ng[(size_t)s0 * noise_N], c->ng.p, (size_t)cnt * noise_N * 8,
-                                 hipMemcpyDeviceToHost, st));
+        HIPCHK(c, c->pin.gather(&ng[(size_t)s0 * noise_N], c->ng.p, (size_t)cnt * noise_N * 8, st));
     }
+    HIPCHK(c, c->pin.flush_down(st));
     HIPCHK(c, hipStreamSynchronize(st));
+    c->pin.finish();
+    memcpy(&logdet[s0], hscal.data(), (size_t)cnt * 8);
+    memcpy(&quad[s0], hscal.data() + cnt, (size_t)cnt * 8);
+    memcpy(hinfo.data(), hscal.data() + 2 * (size_t)cnt, (size_t)cnt * sizeof(int));
     hc.lap("d2h+sync");
     for (int i = 0; i < cnt; ++i) b.info[s0 + i] = hinfo[i];
     if (kmode() && mode == MODE_GRAD)
