@@ -61,14 +61,23 @@ __global__ __launch_bounds__(256) void gemv_sub_kernel(const T* __restrict__ A_a
 constexpr int TRC = 128;  // = TILE, so every padded size is a whole number of chunks
 // Each lane owns VEC adjacent columns (one 16-byte load per row), each wave every fourth row of the chunk,
 // eight loads in flight per lane.   grid = (npad / (64 * VEC), npad / TRC, batch)
+// quad != nullptr: block (0, 0, b) also leaves z[b] . z[b] there -- the arithmetic of dot_kernel, without its launch.
 template <typename T>
 __global__ __launch_bounds__(256) void trmv_t_part_kernel(const T* __restrict__ W_all, long long sW, int ldw,
                                                           const double* __restrict__ z_all, int npad,
-                                                          double* __restrict__ part_all) {
+                                                          double* __restrict__ part_all, double* __restrict__ quad) {
   using vec_t = typename MM<T>::vec_t;
   constexpr int VEC = MM<T>::VEC;
   __shared__ double red[4][64 * VEC];
   const int b = blockIdx.z, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (quad && blockIdx.x == 0 && blockIdx.y == 0) {
+    const double* zz = z_all + (size_t)b * npad;
+    double q = 0.0;
+    for (int i = threadIdx.x; i < npad; i += 256) q += zz[i] * zz[i];
+    q = block_sum_256(q, &red[0][0]);
+    if (threadIdx.x == 0) quad[b] = q;
+    __syncthreads();
+  }
   const int k_raw = (blockIdx.x * 64 + lane) * VEC;
   const int k = min(k_raw, npad - VEC);  // the last block may hang over the edge (npad is a multiple of 128 only)
   const int nch = npad / TRC;
@@ -142,6 +151,37 @@ __global__ __launch_bounds__(256) void mat_t_vec_kernel(const double* __restrict
     s += Mat[((size_t)b * n + i) * P + p] * vec[(size_t)b * vstride + i];
   s = block_sum_256(s, sh4);
   if (threadIdx.x == 0) out[(size_t)b * P + p] = s;
+}
+
+// The three reductions that close a gradient evaluation in ONE launch (each output by the block, in the order, of the
+// kernel it replaces: reduce_parts_kernel, mat_t_vec_kernel x 2).  grid = (P + mean_N + noise_N, batch):
+//   x <  P                : gout[b][x]  = sum_tile part[b][tile][x]
+//   x <  P + mean_N       : mg[b][p]    = sum_i dm[b][i][p] alpha[b][i]
+//   else                  : ng[b][p]    = sum_i dsn2[b][i][p] diagq[b][i]
+__global__ __launch_bounds__(256) void grad_tail_kernel(const double* __restrict__ part, int ntiles, int P,
+                                                        double* __restrict__ gout, const double* __restrict__ dm,
+                                                        int n, int mean_N, const double* __restrict__ alpha,
+                                                        double* __restrict__ mg, const double* __restrict__ dsn2,
+                                                        int noise_N, const double* __restrict__ diagq,
+                                                        double* __restrict__ ng, int vstride) {
+  __shared__ double sh4[4];
+  const int x = blockIdx.x, b = blockIdx.y;
+  double s = 0.0;
+  double* out;
+  if (x < P) {
+    for (int i = threadIdx.x; i < ntiles; i += 256) s += part[((size_t)b * ntiles + i) * P + x];
+    out = gout + (size_t)b * P + x;
+  } else if (x < P + mean_N) {
+    const int p = x - P;
+    for (int i = threadIdx.x; i < n; i += 256) s += dm[((size_t)b * n + i) * mean_N + p] * alpha[(size_t)b * vstride + i];
+    out = mg + (size_t)b * mean_N + p;
+  } else {
+    const int p = x - P - mean_N;
+    for (int i = threadIdx.x; i < n; i += 256) s += dsn2[((size_t)b * n + i) * noise_N + p] * diagq[(size_t)b * vstride + i];
+    out = ng + (size_t)b * noise_N + p;
+  }
+  s = block_sum_256(s, sh4);
+  if (threadIdx.x == 0) *out = s;
 }
 
 // out[b][j] = sum_i A[b][i][j] * Bm[b][i][j]   over rows < nrows.  grid = (mpad/64, batch)

@@ -628,7 +628,13 @@ struct Pipe {
       // (the last counter of the group belongs to the split build, already in flight on the side stream)
       F.ctr = c->tile_ctr.as<int>() + (size_t)gidx * gpc_ctx::CTR_PER_GROUP;
       F.ctr_cap = gpc_ctx::CTR_PER_GROUP - NQ;
-      HIPCHK(c, hipMemsetAsync(F.ctr, 0, (gpc_ctx::CTR_PER_GROUP - NQ) * sizeof(int), st));
+      // (no launch of a small problem is persistent -- its largest, W^T W, has tm (tm + 1) / 2 tiles per sample --
+      // and the zeroing would be a launch of its own on the critical path)
+      const long long tmx = npad / TILE, biggest = tmx * (tmx + 1) / 2 * n;
+      if (defer_node > 0 || biggest >= std::min<long long>(gpc::g_small_launch_blocks, gpc::g_block_slots - gpc::g_persist_spare))
+        HIPCHK(c, hipMemsetAsync(F.ctr, 0, (gpc_ctx::CTR_PER_GROUP - NQ) * sizeof(int), st));
+      else
+        F.ctr = nullptr;
     }
     // NLL only: the inverse of the whole matrix is not needed (only of left children)
     const bool full_inv = (mode != MODE_NLL);
@@ -648,12 +654,13 @@ struct Pipe {
 
     // z = L^-1 r ; quad = z.z ; alpha = W^T z / sl
     F.forward_solve(0, npad, full_inv, rvec, zvec);
-    hipLaunchKernelGGL(dot_kernel, dim3(1, n), dim3(256), 0, st, (const double*)zvec, (const double*)zvec,
-                       npad, npad, d_quad);
-    if (mode != MODE_NLL) {
+    if (mode == MODE_NLL) {
+      hipLaunchKernelGGL(dot_kernel, dim3(1, n), dim3(256), 0, st, (const double*)zvec, (const double*)zvec,
+                         npad, npad, d_quad);
+    } else {  // quad = z.z rides in the first block of the transposed product
       double* tpart = c->tpart.as<double>() + (size_t)off * (npad / TRC) * npad;
       hipLaunchKernelGGL((trmv_t_part_kernel<T>), dim3((npad + 64 * MM<T>::VEC - 1) / (64 * MM<T>::VEC), npad / TRC, n), dim3(256), 0, st, (const T*)Wc,
-                         sM, npad, (const double*)zvec, npad, tpart);
+                         sM, npad, (const double*)zvec, npad, tpart, d_quad);
       hipLaunchKernelGGL(trmv_t_sum_kernel, dim3(npad / 128, n), dim3(128), 0, st, (const double*)tpart, npad,
                          (const double*)spb, (int)SP_STRIDE, (int)SP_SL, avec);
     }
@@ -671,8 +678,16 @@ struct Pipe {
         GPC_COV_DISPATCH(trace_kernel, T, b.cd, dim3(ntl, n), dim3(256), 4 * (((Pn + 3) & ~3) + 4) * sizeof(double), st,
                          b.cd, (const double*)xs, (const double*)spb, (const double*)avec, N, npad, (const T*)Tc, sM,
                          npad, parts, ntl, diagq);
-        hipLaunchKernelGGL(reduce_parts_kernel, dim3(Pn, n), dim3(256), 0, st, (const double*)parts, ntl, Pn,
-                           c->gout.as<double>() + (size_t)off * Pn);
+        // the reduction of the tile partials and the mean / noise gradient products: one launch
+        const int mN = mean_N > 0 ? mean_N : 0, nN = (noise_N > 0 && b.vec_noise) ? noise_N : 0;
+        hipLaunchKernelGGL(grad_tail_kernel, dim3(Pn + mN + nN, n), dim3(256), 0, st, (const double*)parts, ntl, Pn,
+                           c->gout.as<double>() + (size_t)off * Pn,
+                           mN ? (const double*)(c->dmb.as<double>() + (size_t)off * N * mean_N) : nullptr, N, mN,
+                           (const double*)avec, mN ? c->mg.as<double>() + (size_t)off * mean_N : nullptr,
+                           nN ? (const double*)(c->dsn2b.as<double>() + (size_t)off * N * noise_N) : nullptr, nN,
+                           (const double*)diagq, nN ? c->ng.as<double>() + (size_t)off * noise_N : nullptr, npad);
+        HIPCHK(c, hipGetLastError());
+        return 0;
       }
       if (mean_N > 0)
         hipLaunchKernelGGL(mat_t_vec_kernel, dim3(mean_N, n), dim3(256), 0, st,
@@ -1619,7 +1634,7 @@ int append_impl(gpc_post* po, const double* m_star, const double* sn2_star, doub
   // the padding rows of W are identity rows: l[i >= n] = Ks[i] = 0, harmless in W^T l
   double* tpart = c->tpart.as<double>();
   hipLaunchKernelGGL((trmv_t_part_kernel<T>), dim3((npad + 64 * MM<T>::VEC - 1) / (64 * MM<T>::VEC), npad / TRC, S), dim3(256), 0, st,
-                     (const T*)po->W.as<T>(), sM, npad, (const double*)lv, npad, tpart);
+                     (const T*)po->W.as<T>(), sM, npad, (const double*)lv, npad, tpart, (double*)nullptr);
   hipLaunchKernelGGL(trmv_t_sum_kernel, dim3(npad / 128, S), dim3(128), 0, st, (const double*)tpart, npad,
                      (const double*)nullptr, 0, 0, au);
   HIPCHK(c, hipGetLastError());
