@@ -81,6 +81,13 @@ struct XferDesc {
   int nseg;
   void* zero;
   unsigned long long zero8;
+  // optional: the scaled inputs of all samples (covfun.h: scale_x_kernel's arithmetic), mul / dv read from the
+  // staged host copies, so that the first kernel of the pipeline is the covariance build itself
+  const double* X = nullptr;
+  const double* mul = nullptr;
+  const double* dv = nullptr;
+  double* xs = nullptr;
+  int n = 0, npad = 0, D = 0, cnt = 0;
 };
 __global__ __launch_bounds__(256) void xfer_kernel(XferDesc d) {
   const unsigned long long gt = (unsigned long long)blockIdx.x * 256 + threadIdx.x, stride = (unsigned long long)gridDim.x * 256;
@@ -91,6 +98,16 @@ __global__ __launch_bounds__(256) void xfer_kernel(XferDesc d) {
   }
   unsigned long long* z = reinterpret_cast<unsigned long long*>(d.zero);
   for (unsigned long long i = gt; i < d.zero8; i += stride) z[i] = 0ull;
+  if (d.xs) {
+    const unsigned long long per = (unsigned long long)d.npad * d.D, tot = per * d.cnt;
+    for (unsigned long long q = gt; q < tot; q += stride) {
+      const unsigned long long b = q / per, idx = q - b * per;
+      const int i = (int)(idx / d.D), h = (int)(idx % d.D);
+      double v = 0.0;
+      if (i < d.n) v = d.X[(size_t)i * d.D + h] * d.mul[b * d.D + h] / d.dv[b * d.D + h];
+      d.xs[q] = v;
+    }
+  }
 }
 
 struct PinBuf {
@@ -167,22 +184,25 @@ struct PinBuf {
   std::vector<Pending> up_fallback;
   void begin_gather() {
     upd.nseg = downd.nseg = 0;
+    upd.xs = nullptr;
     upd.zero = downd.zero = nullptr;
     upd.zero8 = downd.zero8 = 0;
     up_fallback.clear();
     gathered_bytes = 0;
   }
   size_t gathered_bytes = 0;
-  void stage(void* dst, const void* src, size_t n) {
-    if (n == 0) return;
+  // returns the staged (pinned, device-readable) copy, or nullptr when the segment travels by itself
+  const void* stage(void* dst, const void* src, size_t n) {
+    if (n == 0) return nullptr;
     void* h = (n % 8 == 0 && upd.nseg < XferDesc::MAXSEG && gathered_bytes + n <= kGather) ? alloc(n) : nullptr;
     if (!h) {
       up_fallback.push_back({dst, src, n});
-      return;
+      return nullptr;
     }
     memcpy(h, src, n);
     upd.seg[upd.nseg++] = {dst, h, (unsigned long long)(n / 8)};
     gathered_bytes += n;
+    return h;
   }
   hipError_t flush_up(hipStream_t st, void* zero, size_t zero_bytes) {
     for (Pending& q : up_fallback) {
@@ -197,8 +217,8 @@ struct PinBuf {
     }
     upd.zero = zero;
     upd.zero8 = zero_bytes / 8;
-    if (upd.nseg == 0 && upd.zero8 == 0) return hipSuccess;
-    const unsigned long long words = gathered_bytes / 8 + upd.zero8;
+    if (upd.nseg == 0 && upd.zero8 == 0 && !upd.xs) return hipSuccess;
+    const unsigned long long words = gathered_bytes / 8 + upd.zero8 + (upd.xs ? (unsigned long long)upd.npad * upd.D * upd.cnt : 0ull);
     const int blocks = (int)std::min<unsigned long long>(256, (words + 255) / 256);
     hipLaunchKernelGGL(xfer_kernel, dim3(std::max(1, blocks)), dim3(256), 0, st, upd);
     upd.nseg = 0;
@@ -572,10 +592,12 @@ struct Pipe {
                            (const double*)(c->dvec.as<double>() + (size_t)(off + i) * npad), Ac + (size_t)i * sM);
       }
     } else {
-      const long long tot = (long long)npad * D;
-      dim3 grid((unsigned)((tot + 255) / 256), n);
-      hipLaunchKernelGGL(scale_x_kernel, grid, dim3(256), 0, st, c->dX.as<double>(), N, npad, D,
-                         c->mulb.as<double>() + (size_t)off * D, c->divb.as<double>() + (size_t)off * D, xs);
+      if (!prescaled) {
+        const long long tot = (long long)npad * D;
+        dim3 grid((unsigned)((tot + 255) / 256), n);
+        hipLaunchKernelGGL(scale_x_kernel, grid, dim3(256), 0, st, c->dX.as<double>(), N, npad, D,
+                           c->mulb.as<double>() + (size_t)off * D, c->divb.as<double>() + (size_t)off * D, xs);
+      }
       // With the deferred schedule the build is split: the tiles of the first 1024 rows on this stream, the
       // rest as a persistent, CU-reserving launch on the side stream under the first subtree (plan.h waits
       // for it before the first launch that reads rows >= 1024).
@@ -708,6 +730,7 @@ struct Pipe {
     hipStream_t st = c->st;
     const unsigned long long key[4] = {
         ((unsigned long long)mode << 60) | ((unsigned long long)sizeof(T) << 52) | ((unsigned long long)b.vec_noise << 48) |
+            ((unsigned long long)prescaled << 49) |
             ((unsigned long long)cnt << 24) | (unsigned long long)b.N,
         ((unsigned long long)b.cd.kind << 48) | ((unsigned long long)b.cd.degree << 40) | ((unsigned long long)b.D << 20) |
             ((unsigned long long)mean_N << 10) | (unsigned long long)noise_N,
@@ -758,6 +781,7 @@ struct Pipe {
   int chunk_s0 = 0;  // first sample (batch numbering) of the chunk being processed
   int defer_node = 0;  // plan.h: nodes at least this large run their U product on the side stream (0: none)
   bool split_build = false;
+  bool prescaled = false;  // the transfer kernel of this chunk has written the scaled inputs (run())
   int lauum_n[gpc_ctx::MAXG + 1] = {};
 
   // run the device pipeline for samples [s0, s0+cnt) whose matrices start at slot `slot`.
@@ -816,11 +840,24 @@ struct Pipe {
     HostClock hc("run");
     c->pin.begin();
     c->pin.begin_gather();
-    auto up = [&](void* dst, const void* src, size_t n) { c->pin.stage(dst, src, n); };
+    auto up = [&](void* dst, const void* src, size_t n) { return c->pin.stage(dst, src, n); };
     HIPCHK(c, hipEventRecord(c->ev[0], st));
     up(c->spb.p, &b.sp[(size_t)s0 * SP_STRIDE], (size_t)cnt * SP_STRIDE * 8);
-    up(c->mulb.p, &b.mul[(size_t)s0 * D], (size_t)cnt * D * 8);
-    up(c->divb.p, &b.dv[(size_t)s0 * D], (size_t)cnt * D * 8);
+    const void* hmul = up(c->mulb.p, &b.mul[(size_t)s0 * D], (size_t)cnt * D * 8);
+    const void* hdv = up(c->divb.p, &b.dv[(size_t)s0 * D], (size_t)cnt * D * 8);
+    // the scaled inputs of the whole chunk ride in the transfer kernel (device_section then starts with the build)
+    prescaled = hmul && hdv && !kmode() && (size_t)cnt * npad * D * 8 <= (PinBuf::kGather << 2);
+    if (prescaled) {
+      XferDesc& u = c->pin.upd;
+      u.X = c->dX.as<double>();
+      u.mul = static_cast<const double*>(hmul);
+      u.dv = static_cast<const double*>(hdv);
+      u.xs = c->xs.as<double>();
+      u.n = N;
+      u.npad = npad;
+      u.D = D;
+      u.cnt = cnt;
+    }
     up(c->dvec.p, &b.dvec[(size_t)s0 * npad], cnt * vb);
     up(c->rvec.p, &b.r[(size_t)s0 * npad], cnt * vb);
     if (mode == MODE_GRAD && mean_N > 0) up(c->dmb.p, dm + (size_t)s0 * N * mean_N, (size_t)cnt * N * mean_N * 8);
