@@ -191,7 +191,9 @@ struct Factor {
       gemm(blk(W, o2, o1), sW, blk(W, o2, o2), sW, blk(A, o2, o1), sA, n2, n1, n2, false, true, -1.0,
            0, KLO_ZERO, KHI_ROW, 0);
     }
-    if (keep_L || !need_inv) {
+    // L21 back into A: only where L must survive as the Cholesky factor (posteriors).  The blocked forward solve
+    // of an NLL-only evaluation reads L21 where it was computed, in the scratch (forward_solve below).
+    if (keep_L) {
       dim3 grid(n1 / 64, n2 / 4, batch), block(64, 4);
       hipLaunchKernelGGL((rect_copy_kernel<T>), grid, block, 0, st, (const T*)blk(Tm, o2, o1), sT, npad,
                          blk(A, o2, o1), sA, npad, n2, n1);
@@ -212,7 +214,9 @@ struct Factor {
     const int q = n / TILE;
     const int n1 = (q / 2) * TILE, n2 = n - n1;
     forward_solve(off, n1, true, r, z);
-    hipLaunchKernelGGL((gemv_sub_kernel<T>), dim3(n2 / 4, batch), dim3(256), 0, st, (const T*)A, sA, npad,
+    // L21 of a block without its own inverse is still in the scratch (potrf_inv step 2; nothing has written that
+    // block since), and in A as well when keep_L copied it there: same values
+    hipLaunchKernelGGL((gemv_sub_kernel<T>), dim3(n2 / 4, batch), dim3(256), 0, st, (const T*)Tm, sT, npad,
                        (const double*)z, r, npad, off + n1, off, n1);
     ++launches;
     forward_solve(off + n1, n2, need_inv, r, z);

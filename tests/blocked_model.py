@@ -100,8 +100,8 @@ def potrf_inv(A, W, T, off, n, tile, need_inv, post_mode, log=None):
         # step 5b: W21 = -W22 * U     (W22 lower: k <= row)
         tiled_gemm(W[r2, r1], W[r2, r2], A[r2, r1], n2, n1, n2, tile, a_kmajor=False,
                    b_kmajor=True, alpha=-1.0, beta=0.0, khi=KHI_ROW, log=log)
-    if post_mode or not need_inv:
-        A[r2, r1] = T[r2, r1]  # keep L21 in A (posterior fetch / later solves)
+    if post_mode:
+        A[r2, r1] = T[r2, r1]  # keep L21 in A (posterior fetch); forward_solve reads it from the scratch
     if log is not None:
         log["launches"] = log.get("launches", 0) + (4 if need_inv else 2)
     return 0
@@ -121,10 +121,10 @@ def pad_identity(Amat, tile):
     return P
 
 
-def forward_solve(A, W, r, off, n, tile, need_inv):
+def forward_solve(T, W, r, off, n, tile, need_inv):
     """z = L^-1 r using what potrf_inv(need_inv=...) left behind: a block that has
     its full inverse multiplies by W (trmv); otherwise split like the factorization
-    and use L21 (kept in A for exactly these blocks)."""
+    and use L21, still in the scratch T where step 2 computed it."""
     if need_inv or n == tile:
         s = slice(off, off + n)
         r[s] = np.tril(W[s, s]) @ r[s]
@@ -133,6 +133,6 @@ def forward_solve(A, W, r, off, n, tile, need_inv):
     n1 = (q // 2) * tile if q > 1 else tile
     n2 = n - n1
     r1, r2 = slice(off, off + n1), slice(off + n1, off + n)
-    forward_solve(A, W, r, off, n1, tile, True)
-    r[r2] -= A[r2, r1] @ r[r1]
-    forward_solve(A, W, r, off + n1, n2, tile, need_inv)
+    forward_solve(T, W, r, off, n1, tile, True)
+    r[r2] -= T[r2, r1] @ r[r1]
+    forward_solve(T, W, r, off + n1, n2, tile, need_inv)

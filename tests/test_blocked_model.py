@@ -60,7 +60,7 @@ def test_plan_nll_only_mode_skips_top_level_inverse():
     assert np.allclose(np.diag(A), np.diag(Lref), rtol=1e-12)
     r = rng.standard_normal(n)
     z = r.copy()
-    bm.forward_solve(A, W, z, 0, n, tile, False)
+    bm.forward_solve(T, W, z, 0, n, tile, False)
     assert np.allclose(z, np.linalg.solve(Lref, r), rtol=1e-9, atol=1e-12)
     full = {}
     A2, W2, T2 = A0.copy(), np.zeros((n, n)), np.full((n, n), np.nan)

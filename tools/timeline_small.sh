@@ -20,8 +20,8 @@ import csv,glob
 f=glob.glob("$O/prof/*/*_kernel_trace.csv")[0]
 rows=[r for r in csv.DictReader(open(f))]
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
-# evaluations start at xfer_kernel launches that follow another kernel by > 20 us... simpler: split at scale_x
-idx=[i for i,r in enumerate(rows) if "scale_x" in r["Kernel_Name"]]
+# an evaluation = the transfer kernel before a build_kernel launch .. the transfer kernel before the next
+idx=[i for i,r in enumerate(rows) if "build_kernel" in r["Kernel_Name"]]
 lo=idx[-2]-1; hi=idx[-1]-1
 t0=int(rows[lo]["Start_Timestamp"])
 prev_end=t0
