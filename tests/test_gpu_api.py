@@ -245,3 +245,30 @@ def test_singular_raises_linalg_error():
     with pytest.raises(np.linalg.LinAlgError) as e:
         gp.update(X_new=X, y_new=y, hyp=hyp)
     assert "Singular matrix for L Cholesky decomposition" in str(e.value)
+
+
+def test_gathered_and_individual_transfers_agree():
+    """A call's host arrays travel as ONE gathered transfer (a kernel reading the pinned staging block, which also
+    writes the scaled inputs) up to 2 MB; beyond that, segment by segment, through the copy engines, with the
+    scaled inputs from their own kernel.  A batch large enough to mix the two paths must give, sample for
+    sample, the bits of small batches that fit the gathered path whole (per-point noise and a mean with
+    parameters: every optional segment is present)."""
+    import gpyreg_amd as gpr
+
+    rng = np.random.default_rng(21)
+    N, D, S = 300, 3, 700  # npad = 384: the per-sample vectors alone are 2 x 2.15 MB
+    X = rng.uniform(-3, 3, (N, D))
+    y = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.standard_normal((N, 1))
+    s2 = 0.01 + 0.02 * rng.random((N, 1))
+    gp = gpr.GP(D, gpr.covariance_functions.Matern(5), gpr.mean_functions.NegativeQuadratic(),
+                gpr.noise_functions.GaussianNoise(constant_add=True, user_provided_add=True))
+    hyp0 = np.concatenate([np.log(1.5) * np.ones(D), [0.0], [np.log(0.1)], [0.0], np.zeros(D), np.zeros(D)])
+    hyp = hyp0 + 0.1 * rng.standard_normal((S, hyp0.size))
+    gp.update(X_new=X, y_new=y, s2_new=s2, hyp=hyp[:1], compute_posterior=False)
+    big_n, big_g = gp.nll_batch(hyp, compute_grad=True)
+    for lo in (0, 350, 693):
+        small_n, small_g = gp.nll_batch(hyp[lo:lo + 7], compute_grad=True)
+        assert np.array_equal(small_n, big_n[lo:lo + 7])
+        assert np.array_equal(small_g, big_g[lo:lo + 7])
+    nll_only = gp.nll_batch(hyp, compute_grad=False)[0]
+    assert np.array_equal(nll_only[:7], gp.nll_batch(hyp[:7], compute_grad=False)[0])
