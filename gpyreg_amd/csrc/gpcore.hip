@@ -46,6 +46,16 @@ struct DevBuf {
     if (e == hipSuccess) bytes = need;
     return e;
   }
+  // for buffers no captured launch graph refers to (a posterior's private constants): no epoch bump
+  hipError_t ensure_private(size_t need) {
+    if (need <= bytes) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    hipError_t e = hipMalloc(&p, need);
+    if (e == hipSuccess) bytes = need;
+    return e;
+  }
   void release() {
     if (p) (void)hipFree(p);
     p = nullptr;
@@ -354,6 +364,11 @@ struct gpc_post {
   std::vector<double> sp, mul, dv;  // host copies of per-sample scalars (SP_STRIDE), scaling
   std::vector<double> sW, mult;
   std::vector<int> lchol, info;
+  // What every predict / quad call of this posterior needs again -- the per-sample scalars, the input scaling and
+  // the scaled training inputs -- stays on the device once the first call has put it there (three uploads and a
+  // kernel less per call); any change of sp / mul / dv / N clears the flag.
+  DevBuf dsp, dmul, ddv, dxs;
+  bool dev_consts = false;
 };
 
 #define HIPCHK(ctx, expr)                                                                   \
@@ -1273,6 +1288,7 @@ int post_impl(gpc_ctx* c, Batch& b, gpc_post* po, double* sn2_mult, int* L_chol,
     HIPCHK(c, hipStreamSynchronize(c->st));
   }
   hc.lap("device");
+  po->dev_consts = false;
   po->sp = b.sp;
   po->mul = b.mul;
   po->dv = b.dv;
@@ -1351,29 +1367,50 @@ int rhs_products(gpc_post* po, int mode, const double* xa, const double* xb, int
   if (full && (size_t)M * M * 8 >= PinBuf::kMin && (size_t)M * M * 8 <= PinBuf::kMax)
     hfull = static_cast<double*>(c->pin.alloc((size_t)M * M * 8));
 
+  // all samples in one chunk (the usual case): the posterior's constants are resident, see gpc_post
+  const bool resident = chunk == S && mode != 2;
+  if (resident && !po->dev_consts) {
+    HIPCHK(c, po->dsp.ensure_private((size_t)S * SP_STRIDE * 8));
+    HIPCHK(c, po->dmul.ensure_private((size_t)S * D * 8));
+    HIPCHK(c, po->ddv.ensure_private((size_t)S * D * 8));
+    HIPCHK(c, po->dxs.ensure_private((size_t)S * npad * D * 8));
+    HIPCHK(c, hipMemcpyAsync(po->dsp.p, po->sp.data(), (size_t)S * SP_STRIDE * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(po->dmul.p, po->mul.data(), (size_t)S * D * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(po->ddv.p, po->dv.data(), (size_t)S * D * 8, hipMemcpyHostToDevice, st));
+    const long long tot = (long long)npad * D;
+    hipLaunchKernelGGL(scale_x_kernel, dim3((unsigned)((tot + 255) / 256), S), dim3(256), 0, st, c->dX.as<double>(), N,
+                       npad, D, po->dmul.as<double>(), po->ddv.as<double>(), po->dxs.as<double>());
+    HIPCHK(c, hipGetLastError());
+    po->dev_consts = true;
+  }
+  const double* spb = resident ? po->dsp.as<double>() : c->spb.as<double>();
+  const double* mulb = resident ? po->dmul.as<double>() : c->mulb.as<double>();
+  const double* divb = resident ? po->ddv.as<double>() : c->divb.as<double>();
+  const double* xsb = resident ? po->dxs.as<double>() : c->xs.as<double>();
+
   for (int s0 = 0; s0 < S; s0 += chunk) {
     const int cnt = std::min(chunk, S - s0);
-    HIPCHK(c, hipMemcpyAsync(c->spb.p, &po->sp[(size_t)s0 * SP_STRIDE], (size_t)cnt * SP_STRIDE * 8,
-                             hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->mulb.p, &po->mul[(size_t)s0 * D], (size_t)cnt * D * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->divb.p, &po->dv[(size_t)s0 * D], (size_t)cnt * D * 8, hipMemcpyHostToDevice, st));
+    if (!resident) {
+      HIPCHK(c, hipMemcpyAsync(c->spb.p, &po->sp[(size_t)s0 * SP_STRIDE], (size_t)cnt * SP_STRIDE * 8,
+                               hipMemcpyHostToDevice, st));
+      HIPCHK(c, hipMemcpyAsync(c->mulb.p, &po->mul[(size_t)s0 * D], (size_t)cnt * D * 8, hipMemcpyHostToDevice, st));
+      HIPCHK(c, hipMemcpyAsync(c->divb.p, &po->dv[(size_t)s0 * D], (size_t)cnt * D * 8, hipMemcpyHostToDevice, st));
+    }
     T* Ks = c->ks.as<T>();
     T* V = c->vb.as<T>();
     if (mode == 0) {
       long long tot = (long long)npad * D;
-      hipLaunchKernelGGL(scale_x_kernel, dim3((unsigned)((tot + 255) / 256), cnt), dim3(256), 0, st,
-                         c->dX.as<double>(), N, npad, D, c->mulb.as<double>(), c->divb.as<double>(),
-                         c->xs.as<double>());
+      if (!resident)
+        hipLaunchKernelGGL(scale_x_kernel, dim3((unsigned)((tot + 255) / 256), cnt), dim3(256), 0, st,
+                           c->dX.as<double>(), N, npad, D, mulb, divb, c->xs.as<double>());
       tot = (long long)mpad * D;
       hipLaunchKernelGGL(scale_x_kernel, dim3((unsigned)((tot + 255) / 256), cnt), dim3(256), 0, st,
-                         (const double*)d_xa, M, mpad, D, c->mulb.as<double>(), c->divb.as<double>(),
-                         c->xss.as<double>());
-      hipLaunchKernelGGL((cross_kernel<T>), dim3(mpad / 64, npad / 4, cnt), dim3(64, 4), 0, st, po->cd,
-                         c->xs.as<double>(), c->xss.as<double>(), c->spb.as<double>(), N, npad, M, mpad, Ks, sKs);
+                         (const double*)d_xa, M, mpad, D, mulb, divb, c->xss.as<double>());
+      hipLaunchKernelGGL((cross_kernel<T>), dim3(mpad / 64, npad / 4, cnt), dim3(64, 4), 0, st, po->cd, xsb,
+                         c->xss.as<double>(), spb, N, npad, M, mpad, Ks, sKs);
       if (full)
         hipLaunchKernelGGL((cross_kernel<T>), dim3(mpad / 64, mpad / 4, cnt), dim3(64, 4), 0, st, po->cd,
-                           c->xss.as<double>(), c->xss.as<double>(), c->spb.as<double>(), M, mpad, M, mpad,
-                           c->kss.as<T>(), sKss);
+                           c->xss.as<double>(), c->xss.as<double>(), spb, M, mpad, M, mpad, c->kss.as<T>(), sKss);
     } else if (mode == 2) {
       // caller-provided cross covariances Ks_s (N x M doubles, xa) and, with `full`, K**_s (M x M, xb)
       HIPCHK(c, c->dbg1.ensure((size_t)std::max(N, M) * M * sizeof(double)));
@@ -1389,8 +1426,8 @@ int rhs_products(gpc_post* po, int mode, const double* xa, const double* xb, int
       }
     } else {
       hipLaunchKernelGGL((quad_z_kernel<T>), dim3(mpad / 64, npad / 4, cnt), dim3(64, 4), 0, st,
-                         c->dX.as<double>(), (const double*)d_xa, (const double*)d_xb, c->mulb.as<double>(),
-                         c->divb.as<double>(), c->spb.as<double>(), N, npad, M, mpad, D, Ks, sKs);
+                         c->dX.as<double>(), (const double*)d_xa, (const double*)d_xb, mulb, divb, spb, N, npad, M, mpad,
+                         D, Ks, sKs);
     }
     double* d_mu = c->pout.as<double>();
     double* d_v = d_mu + (size_t)chunk * mpad;
@@ -1745,6 +1782,7 @@ int append_impl(gpc_post* po, const double* m_star, const double* sn2_star, doub
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(st));
   po->N = n + 1;
+  po->dev_consts = false;
   return 0;
 }
 }  // namespace
@@ -2105,6 +2143,10 @@ int gpc_post_free(gpc_post* po) {
   po->ctx->pool_give(po->A);
   po->ctx->pool_give(po->W);
   po->ctx->pool_give(po->alpha);
+  po->dsp.release();
+  po->dmul.release();
+  po->ddv.release();
+  po->dxs.release();
   delete po;
   return 0;
 }
@@ -2160,6 +2202,7 @@ int gpc_post_recompute(gpc_post* po, int cnt, const int* idx, const double* hyp_
         rc = -1;
         break;
       }
+      po->dev_consts = false;
       std::copy_n(&tmp.sp[(size_t)i * SP_STRIDE], SP_STRIDE, &po->sp[(size_t)s * SP_STRIDE]);
       std::copy_n(&tmp.mul[(size_t)i * po->D], po->D, &po->mul[(size_t)s * po->D]);
       std::copy_n(&tmp.dv[(size_t)i * po->D], po->D, &po->dv[(size_t)s * po->D]);
