@@ -596,8 +596,12 @@ class GP:
         if sampler_name != "slicesample":
             raise ValueError("Unknown sampler!")
         widths = widths_default if widths is None else np.minimum(widths, widths_default)
+        # (the shrinkage proposals of a coordinate are evaluated four at a time, see slice_sample.py; the chain is
+        # the sequential sampler's)
         slicer = SliceSampler(lambda h: self.__gp_obj_fun(h, False, True), hyp_start, widths, LB, UB,
-                              {"display": "off", "diagnostics": False})
+                              {"display": "off", "diagnostics": False,
+                               "log_f_batch": lambda H: -self._obj_batch(H, False),
+                               "speculate": int(options.get("slice_speculate", 4)) if isinstance(options, dict) else 4})
         sampling_result = slicer.sample(s_N * thin, burn=burn_in)
         hyp = sampling_result["samples"][thin - 1::thin, :]
 

@@ -121,3 +121,34 @@ def test_slice_sampler_moments():
     s = SliceSampler(lambda x: -0.5 * np.sum((x - 3) ** 2), np.array([0.5]), None, np.array([0.0]), np.array([1.0]))
     xs = s.sample(500)["samples"]
     assert xs.min() >= 0 and xs.max() <= 1 and xs.mean() > 0.55
+
+
+def test_speculative_slice_sampler_walks_the_sequential_chain():
+    """The shrinkage proposals of a coordinate update do not depend on the target's values, only the point at which
+    they stop does: evaluated four at a time (one device batch), with the global RNG rewound to the draws the
+    sequential procedure makes, the sampler must return the same samples, values, adapted widths and leave the
+    same RNG stream behind -- with fewer calls.  A batch that raises hands the coordinate back to the sequential loop."""
+    from gpyreg_amd.slice_sample import SliceSampler
+
+    scale = np.array([1.0, 0.3, 2.0])
+
+    def logf(x):
+        return float(-0.5 * np.sum((x / scale) ** 2) + np.log1p(0.5 * np.cos(3 * x[0]) ** 2))
+
+    calls = {"n": 0}
+
+    def logf_batch(X):
+        calls["n"] += 1
+        if calls["n"] % 7 == 0:
+            raise np.linalg.LinAlgError("a speculative row failed")
+        return np.array([logf(x) for x in X])
+
+    out = []
+    for batch in (None, logf_batch):
+        np.random.seed(5)
+        s = SliceSampler(logf, np.zeros(3), None, -4 * np.ones(3), 4 * np.ones(3), {"log_f_batch": batch, "speculate": 4})
+        r = s.sample(120, thin=2, burn=40)
+        out.append((r["samples"], r["f_vals"], s.widths.copy(), np.random.rand(), s.func_count, s.device_calls))
+    (sa, fa, wa, ra, na, da), (sb, fb, wb, rb, nb, db) = out
+    assert np.array_equal(sa, sb) and np.array_equal(fa, fb) and np.array_equal(wa, wb) and ra == rb
+    assert na == nb and db < 0.75 * da
