@@ -354,6 +354,20 @@ class GP:
                     nlz[s] -= self.__compute_log_priors(hyp[s], False)
         return (nlz, dnlz) if compute_grad else nlz
 
+    def _neg_obj_rows(self, hyp):
+        """One device batch for the rows of ``hyp``; returns row -> ``__gp_obj_fun(hyp[row], False, True)``, the log
+        prior of a row being evaluated when (and only if) the row is asked for."""
+        hyp = np.atleast_2d(np.asarray(hyp, dtype=float))
+        nlz, _ = self.nll_batch(hyp, False)
+
+        def value(k):
+            v = float(nlz[k])
+            if self.no_prior is not True:
+                v -= self.__compute_log_priors(hyp[k], False)
+            return -v
+
+        return value
+
     # ------------------------------------------------------------------ bounds and priors
     def _hyp_N(self):
         return sum(self._counts())
@@ -600,7 +614,7 @@ class GP:
         # the sequential sampler's)
         slicer = SliceSampler(lambda h: self.__gp_obj_fun(h, False, True), hyp_start, widths, LB, UB,
                               {"display": "off", "diagnostics": False,
-                               "log_f_batch": lambda H: -self._obj_batch(H, False),
+                               "log_f_batch": self._neg_obj_rows,
                                "speculate": int(options.get("slice_speculate", 4)) if isinstance(options, dict) else 4})
         sampling_result = slicer.sample(s_N * thin, burn=burn_in)
         hyp = sampling_result["samples"][thin - 1::thin, :]

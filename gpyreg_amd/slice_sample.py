@@ -98,9 +98,12 @@ class SliceSampler:
             inside = ~(np.any(pts < self.LB, axis=1) | np.any(pts > self.UB, axis=1))
             vals = np.full(len(props), -np.inf)
             raw = [None] * len(props)
+            f = None
             if np.any(inside):
                 try:
-                    f = np.asarray(self.log_f_batch(pts[inside]), dtype=float)
+                    # an array of values, or a callable row -> value (the host-side part of the target, e.g. the
+                    # log prior, is then only evaluated for the rows the sequential procedure would have reached)
+                    f = self.log_f_batch(pts[inside])
                 except Exception:
                     # a proposal the sequential procedure might never have reached failed (e.g. a matrix that
                     # stays non-positive-definite): hand the rest of this coordinate to the sequential loop
@@ -108,11 +111,13 @@ class SliceSampler:
                     x_l[dd], x_r[dd] = lo, hi
                     return None, None, None, shrink
                 self.device_calls += 1
-                for k, fk in zip(np.flatnonzero(inside), f):
-                    raw[k] = fk
-                    vals[k] = -np.inf if np.isnan(fk) else float(fk)
+            row_of = np.cumsum(inside) - 1
             taken = len(props)
             for k, xp in enumerate(props):
+                if inside[k]:
+                    fk = f(int(row_of[k])) if callable(f) else f[int(row_of[k])]
+                    raw[k] = fk
+                    vals[k] = -np.inf if np.isnan(fk) else float(fk)
                 if vals[k] > log_u or xp == xx[dd]:
                     taken = k + 1
                     break
