@@ -34,4 +34,4 @@ pr.enable()
 gp.fit(X=X, y=y, options={"n_samples": ns})
 pr.disable()
 print(f"fit N={N} D={D} n_samples={ns}: {time.perf_counter() - t0:.3f} s", flush=True)
-pstats.Stats(pr).sort_stats("tottime").print_stats(30)
+pstats.Stats(pr).sort_stats("cumulative").print_stats(40)
