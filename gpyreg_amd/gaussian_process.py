@@ -610,12 +610,12 @@ class GP:
         if sampler_name != "slicesample":
             raise ValueError("Unknown sampler!")
         widths = widths_default if widths is None else np.minimum(widths, widths_default)
-        # (the shrinkage proposals of a coordinate are evaluated four at a time, see slice_sample.py; the chain is
-        # the sequential sampler's)
+        # (the shrinkage proposals of a coordinate are evaluated several at a time, see slice_sample.py; the chain is
+        # the sequential sampler's.  Measured: 8 per batch up to N = 1000, 6 beyond -- tools/fit_time.py)
         slicer = SliceSampler(lambda h: self.__gp_obj_fun(h, False, True), hyp_start, widths, LB, UB,
                               {"display": "off", "diagnostics": False,
                                "log_f_batch": self._neg_obj_rows,
-                               "speculate": int(options.get("slice_speculate", 4)) if isinstance(options, dict) else 4})
+                               "speculate": int(options.get("slice_speculate", 8 if self.X.shape[0] <= 1024 else 6))})
         sampling_result = slicer.sample(s_N * thin, burn=burn_in)
         hyp = sampling_result["samples"][thin - 1::thin, :]
 

@@ -8,11 +8,11 @@ batched ("replicas only"); each ``log_f`` call is one device NLL eval
 Speculative shrinkage (``options["log_f_batch"]``).  Within one coordinate update the sequence of shrinkage
 proposals does not depend on the target's values: a rejected proposal shrinks the interval to itself on its side of
 the current point, and the next proposal is one uniform draw in the new interval.  Only WHERE the sequence stops
-does.  So the next ``speculate`` proposals are generated ahead, evaluated as ONE device batch (a batch of four costs
+does.  So the next ``speculate`` proposals are generated ahead, evaluated as ONE device batch (a batch of eight costs
 about what a single evaluation does at the sizes the sampler runs at, and its rows carry the bits of single
 evaluations), and the first accepted one is taken; the global RNG is then rewound and advanced by exactly the
 draws the sequential procedure would have made.  The chain, the widths and the RNG stream afterwards are those of
-the sequential sampler; a fit makes ~2.5 times fewer device calls.
+the sequential sampler; a fit makes about a third of the device calls.
 
 This implementation draws from the global NumPy RNG in the same order as the reference
 (one coordinate shuffle per sweep; per coordinate a slice level, an interval offset, then

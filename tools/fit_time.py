@@ -22,11 +22,14 @@ for N, D in ((100, 2), (300, 3), (1000, 5), (2000, 5)):
 
     make().fit(X=X, y=y, options={"n_samples": 10})
     res = {}
-    for spec in (1, 4):
+    for spec in (1, 4, 0):
         gp = make()
         np.random.seed(4)
         t0 = time.perf_counter()
-        hyp, _, _ = gp.fit(X=X, y=y, options={"n_samples": 10, "slice_speculate": spec})
+        opts = {"n_samples": 10}
+        if spec:
+            opts["slice_speculate"] = spec
+        hyp, _, _ = gp.fit(X=X, y=y, options=opts)
         res[spec] = (time.perf_counter() - t0, hyp)
-    same = np.array_equal(res[1][1], res[4][1])
-    print(f"fit N={N:5d} D={D}: sequential sampler {res[1][0]:.3f} s, speculative {res[4][0]:.3f} s, same samples: {same}", flush=True)
+    same = np.array_equal(res[1][1], res[4][1]) and np.array_equal(res[1][1], res[0][1])
+    print(f"fit N={N:5d} D={D}: sequential {res[1][0]:.3f} s, speculate 4: {res[4][0]:.3f} s, default: {res[0][0]:.3f} s, same samples: {same}", flush=True)
