@@ -19,12 +19,30 @@ import numpy as np
 import scipy.stats as sst
 
 from .priors import (
+    _S2PI,
+    _t_norm,
     smoothbox_cdf,
-    smoothbox_ppf,
     smoothbox_student_t_cdf,
-    smoothbox_student_t_ppf,
     uuinv,
 )
+
+
+def _piecewise_ppf(q, C, a, b, mid, tail_ppf):
+    """priors.smoothbox_ppf / smoothbox_student_t_ppf for a whole column at once (the scalar functions, called
+    once per design point, were a third of the design stage): the same three branches, each evaluated with the
+    same elementwise expressions on the points that fall into it."""
+    q = np.asarray(q, dtype=float)
+    out = np.empty(q.shape)
+    low = q < 0.5 / C
+    mid_m = ~low & (q <= (C - 0.5) / C)
+    high = ~low & ~mid_m
+    if np.any(low):
+        out[low] = tail_ppf(C * q[low], a)
+    if np.any(mid_m):
+        out[mid_m] = mid(q[mid_m])
+    if np.any(high):
+        out[high] = tail_ppf(C * q[high] - (C - 1), b)
+    return out
 
 
 def design_points(x0, LB, UB, PLB, PUB, hprior, N, design="sobol"):
@@ -68,12 +86,17 @@ def design_points(x0, LB, UB, PLB, PUB, hprior, N, design="sobol"):
             if df == 0:
                 lo, hi = smoothbox_cdf(LB[i], sigma, a, b), smoothbox_cdf(UB[i], sigma, a, b)
                 q = lo + (hi - lo) * u
-                sX[:, i] = [smoothbox_ppf(v, sigma, a, b) for v in q]
+                C = 1.0 + (b - a) / (sigma * _S2PI)
+                sX[:, i] = _piecewise_ppf(q, C, a, b, lambda v: (v * C - 0.5) * sigma * _S2PI + a,
+                                          lambda v, edge: sst.norm.ppf(v, loc=edge, scale=sigma))
             else:
                 lo = smoothbox_student_t_cdf(LB[i], df, sigma, a, b)
                 hi = smoothbox_student_t_cdf(UB[i], df, sigma, a, b)
                 q = lo + (hi - lo) * u
-                sX[:, i] = [smoothbox_student_t_ppf(v, df, sigma, a, b) for v in q]
+                c = _t_norm(df, sigma)
+                C = 1.0 + (b - a) * c
+                sX[:, i] = _piecewise_ppf(q, C, a, b, lambda v: (v * C - 0.5) / c + a,
+                                          lambda v, edge: sst.t.ppf(v, df, loc=edge, scale=sigma))
         elif df == 0:  # Gaussian
             lo, hi = sst.norm.cdf((LB[i] - mu) / sigma), sst.norm.cdf((UB[i] - mu) / sigma)
             sX[:, i] = sst.norm.ppf(lo + (hi - lo) * u) * sigma + mu
