@@ -884,6 +884,11 @@ struct Pipe {
     hc.lap("h2d");
     int groups = c->groups;
     if (cnt < 2 * groups || npad < 1024 || kmode()) groups = 1;
+    // Two sample groups on two streams pay for their half-size launches only when the batch is large: measured with
+    // the final kernels (tools/batch_latency.py), one group is faster up to S (npad/4096)^3 = 64 in both modes --
+    // N=1000 S=8: 0.78 -> 0.54 ms (NLL), 0.92 -> 0.68 ms (gradient); N=2000 S=8 NLL 1.78 -> 1.36 ms; cfg3 NLL-only
+    // 9.44 -> 9.04 ms -- and two groups by 1-2 % beyond (N=4096 S=128).
+    if ((double)cnt * std::pow((double)npad / 4096.0, 3.0) <= 64.0) groups = 1;
     // Deferred inverse products (plan.h): measured on MI355X (tools/defer_sweep.py) they pay whenever the
     // latency-bound phases are a visible share of the batch -- S (npad/4096)^3 <= 64 with at least 4 samples:
     // N=2048 S=16 4.42 -> 4.04 ms, N=4096 S=4 8.59 -> 7.47, N=4096 S=16 21.5 -> 20.2, N=4096 S=32 39.4 -> 38.7
