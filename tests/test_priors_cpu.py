@@ -152,3 +152,53 @@ def test_speculative_slice_sampler_walks_the_sequential_chain():
     (sa, fa, wa, ra, na, da), (sb, fb, wb, rb, nb, db) = out
     assert np.array_equal(sa, sb) and np.array_equal(fa, fb) and np.array_equal(wa, wb) and ra == rb
     assert na == nb and db < 0.75 * da
+
+
+def test_log_priors_rows_is_bit_identical_to_the_row_loop(g):
+    """The vectorised prior evaluation of the design stage against ``log_priors`` row by row: the reference-pinned
+    configurations of prior_cases.npz, and random mixtures of all six classes (one smooth-box dimension of each kind,
+    so that the vectorised branch runs; several of them take the row loop by design)."""
+    cases = []
+    for name in g["names"]:
+        tag = str(name).split("|")[0]
+        hp = {k: g[tag + "_" + k] for k in ("mu", "sigma", "df", "a", "b")}
+        cases.append((hp, g[tag + "_lb"], g[tag + "_ub"], g[tag + "_H"]))
+    rng = np.random.default_rng(11)
+    for trial in range(30):
+        D = 9
+        hp = pr.empty_priors(D)
+        kinds = rng.permutation(["gauss", "gauss", "stud", "stud", "sb", "sb_t", "uni", "fixed", "gauss"])
+        lb, ub = np.full(D, -8.0), np.full(D, 8.0)
+        for i, k in enumerate(kinds):
+            if k == "gauss":
+                hp["mu"][i], hp["sigma"][i], hp["df"][i] = rng.normal(), 0.3 + rng.random(), 0
+            elif k == "stud":
+                hp["mu"][i], hp["sigma"][i], hp["df"][i] = rng.normal(), 0.3 + rng.random(), rng.integers(1, 8)
+            elif k == "sb":
+                hp["a"][i], hp["b"][i], hp["sigma"][i], hp["df"][i] = -1 - rng.random(), 1 + rng.random(), 0.5 + rng.random(), 0
+            elif k == "sb_t":
+                hp["a"][i], hp["b"][i], hp["sigma"][i], hp["df"][i] = -1 - rng.random(), 1 + rng.random(), 0.5 + rng.random(), 3
+            elif k == "fixed":
+                lb[i] = ub[i] = 0.25
+        H = rng.uniform(-4, 4, (40, D))
+        H[:, kinds == "fixed"] = 0.25
+        H[3, kinds == "fixed"] = 0.3  # off the fixed value: -inf
+        H[5, 0] = np.nan
+        cases.append((hp, lb, ub, H))
+    compared = 0
+    for hp, lb, ub, H in cases:
+        norm = pr.normalization_constants(hp, lb, ub)
+        try:
+            rows = [pr.log_priors(h, hp, lb, ub, norm, True) for h in H]
+        except ValueError:  # the reference's broadcasting error (three smooth-box dimensions): the same on both paths
+            with pytest.raises(ValueError):
+                pr.log_priors_rows(H, hp, lb, ub, norm, True)
+            continue
+        lp, dlp = pr.log_priors_rows(H, hp, lb, ub, norm, True)
+        lp0, none = pr.log_priors_rows(H, hp, lb, ub, norm, False)
+        assert none is None
+        for r, (v, d) in enumerate(rows):
+            assert np.array_equal(np.float64(v), lp[r], equal_nan=True) and np.array_equal(d, dlp[r], equal_nan=True)
+            assert np.array_equal(lp0[r], lp[r], equal_nan=True)
+            compared += 1
+    assert compared >= 1000
