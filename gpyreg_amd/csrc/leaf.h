@@ -523,18 +523,20 @@ __device__ __forceinline__ void update_panel(typename MM<T>::acc_t (&S)[3][8], S
     }
     acc_t c;
     const T* dL = sh.diagL[P & 1];
+    T lpp[4];  // L_PP is read BEFORE this panel's last hand-off: the diag wave may reuse the buffer two chains later
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int row = MM<T>::row_of(lane, e);
       c[e] = dW[row * LDC + l15];
       ur[row * LDR + 16 * P + l15] = c[e];
+      lpp[e] = dL[row * LDC + l15];
     }
     S[RP][P] = c;
     post(&sh.arrivedW, P + 1);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int row = MM<T>::row_of(lane, e);
-      if (l15 <= row) Ab[(size_t)(16 * P + row) * lda + 16 * P + l15] = dL[row * LDC + l15];
+      if (l15 <= row) Ab[(size_t)(16 * P + row) * lda + 16 * P + l15] = lpp[e];
     }
   }
   LEAF_TS(U + 1, P, 3);
