@@ -525,12 +525,13 @@ __device__ __forceinline__ void update_panel(typename MM<T>::acc_t (&S)[3][8], S
     const T* dL = sh.diagL[P & 1];
     T lpp[4];  // L_PP is read BEFORE this panel's last hand-off: the diag wave may reuse the buffer two chains later
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < 4; ++e) {  // all reads first: an LDS write between them makes every read a round trip
       const int row = MM<T>::row_of(lane, e);
       c[e] = dW[row * LDC + l15];
-      ur[row * LDR + 16 * P + l15] = c[e];
       lpp[e] = dL[row * LDC + l15];
     }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ur[MM<T>::row_of(lane, e) * LDR + 16 * P + l15] = c[e];
     S[RP][P] = c;
     post(&sh.arrivedW, P + 1);
 #pragma unroll
