@@ -34,8 +34,16 @@ namespace gpc {
 // amortised equally in both precisions
 template <typename T>
 constexpr int BKT_v = sizeof(T) == 4 ? 32 : 16;
+// m-major LDS image [BT][k].  fp64: rows padded to 17 elements, filled with 8-byte stores; the fragment reads are
+// conflict free, the stores are not (~5e8 conflict cycles per cfg3 step), without costing MFMA issue (measured: the
+// swizzled form below is +-0 on cfg3 / cfg5).  fp32 (MM_SWZ): rows of exactly one k-slab (32 floats = 8 chunks of 16
+// bytes = 32 banks), chunk j of row r stored at chunk j ^ ((r >> 1) & 7): the copy writes whole 16-byte vectors
+// (ds_write_b128: 16 lanes = two rows x 8 chunks = all 64 banks once) and the fragment reads of 16 rows x 4 k hit 64
+// distinct banks as well -- cfg4 42.0 -> 40.4 ms (+3.9 %).
 template <typename T>
-constexpr int LDQ_v = BKT_v<T> + 1;  // stride of an m-major LDS image  [BT][17 | 33]
+constexpr bool MM_SWZ = sizeof(T) == 4;
+template <typename T>
+constexpr int LDQ_v = MM_SWZ<T> ? BKT_v<T> : BKT_v<T> + 1;  // stride of an m-major LDS image
 // stride of a k-major LDS image [16][BT+16]; elements reserved per operand per stage
 constexpr int ldp_of(int BT) { return BT + 16; }
 template <typename T>
@@ -127,8 +135,12 @@ __device__ __forceinline__ void r2s(T* __restrict__ s,
     for (int p = 0; p < NV; ++p) {
       const int row = t / TPR + p * RPP;
       const int kc = (t % TPR) * VEC;
+      if constexpr (MM_SWZ<T>) {
+        *reinterpret_cast<vec_t*>(s + row * LDQ_v<T> + (((t % TPR) ^ ((row >> 1) & 7)) * VEC)) = r[p];
+      } else {
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) s[row * LDQ_v<T> + kc + e] = r[p][e];
+        for (int e = 0; e < VEC; ++e) s[row * LDQ_v<T> + kc + e] = r[p][e];
+      }
     }
   } else {
     constexpr int VPR = BT / VEC;
@@ -144,8 +156,15 @@ __device__ __forceinline__ void r2s(T* __restrict__ s,
 
 template <typename T, bool KM, int BT>
 __device__ __forceinline__ T frag(const T* __restrict__ s, int r0, int kk, int lane) {
-  if constexpr (!KM)
-    return s[(r0 + (lane & 15)) * LDQ_v<T> + kk + (lane >> 4)];
+  if constexpr (!KM) {
+    if constexpr (MM_SWZ<T>) {
+      constexpr int VEC = MM<T>::VEC;
+      const int k = kk + (lane >> 4), l15 = lane & 15;  // r0 is a multiple of 16: the row's key is (l15 >> 1) & 7
+      return s[(r0 + l15) * LDQ_v<T> + (((k / VEC) ^ ((l15 >> 1) & 7)) * VEC) + (k % VEC)];
+    } else {
+      return s[(r0 + (lane & 15)) * LDQ_v<T> + kk + (lane >> 4)];
+    }
+  }
   else
     return s[(kk + (lane >> 4)) * ldp_of(BT) + r0 + (lane & 15)];
 }
