@@ -900,6 +900,11 @@ struct Pipe {
         defer_node = c->defer_min;
       else if (cnt >= 4 && npad >= 2048 && work <= 64.0)
         defer_node = (npad / 2 / TILE) * TILE;
+      // one or two samples of a large problem: the right child of the root is latency-bound for a long stretch
+      // (top two levels, as above: N=8192 S=1 12.95 -> 12.2 ms, S=2 20.87 -> 19.97 ms; N=16384 fp32 S=1 40.0 -> 38.9 ms;
+      // N=4096 S=1 loses 2 %, so not below work = 8)
+      else if (cnt < 4 && work >= 8.0 && work <= 64.0)
+        defer_node = (npad / 2 / TILE) * TILE;
       if (defer_node > 0) groups = 1;
     }
     if (groups == 1 && c->graph_max_npad > 0 && npad <= c->graph_max_npad && !kmode()) {
