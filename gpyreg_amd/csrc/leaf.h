@@ -539,6 +539,15 @@ __device__ __forceinline__ void update_panel(typename MM<T>::acc_t (&S)[3][8], S
       const int row = MM<T>::row_of(lane, e);
       if (l15 <= row) Ab[(size_t)(16 * P + row) * lda + 16 * P + l15] = lpp[e];
     }
+    // row P of the inverse is final: to memory now, while the other waves update, instead of at the end of the kernel
+    // (the last panel's tiles beyond LAST_SHARE are stored by the waves that computed them)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (P == 7 && j >= NJ && j < 7) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        Wb[(size_t)(16 * P + MM<T>::row_of(lane, e)) * ldw + 16 * j + l15] = (j <= P) ? S[RP][j][e] : (T)0;
+    }
   }
   LEAF_TS(U + 1, P, 3);
   if constexpr (trow(U, 0) > P) {
@@ -644,9 +653,9 @@ __device__ __forceinline__ void update_wave(Shared<T>& sh, T* __restrict__ Ab, i
   static_for<0, 3>([&](auto rc) {
     constexpr int r = decltype(rc)::value, i = trow(U, r);
     if constexpr (i >= 0) {
+      if (i < np) return;  // rows that were a panel row went to memory when they became final (update_panel)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        if (i == 7 && j >= 3 && j < 7 && np == 8) continue;  // stored by the waves that computed them (last panel)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int row = 16 * i + MM<T>::row_of(lane, e), col = 16 * j + l15;
