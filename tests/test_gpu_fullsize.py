@@ -281,3 +281,29 @@ def test_dual_launches_do_not_change_a_bit():
     finally:
         bench.CONFIGS[3] = bench_cfg
         ctx.set_option("dual_launch", 1)
+
+
+def test_pipelined_leaf_does_not_change_a_bit_of_the_pipeline():
+    """The whole path -- NLL, gradient, posteriors, predictions -- with the pipelined leaf (default) and with the
+    phase-ordered one it replaced: identical bit for bit (N = 700 and 2304, incl. a padded last leaf; fp64 and fp32)."""
+    import bench
+    from gpyreg_amd import _lib
+
+    ctx = _lib.context(0)
+    bench_cfg = dict(bench.CONFIGS[3])
+    try:
+        for N, S, dtype in ((700, 3, "f64"), (2304, 5, "f64"), (700, 3, "f32")):
+            bench.CONFIGS[3] = dict(bench_cfg, N=N)
+            X, y, hyp = bench.synthetic_problem(3, S)
+            xs = X[:33] + 0.01
+            res = []
+            for leaf in (3, 5):
+                ctx.set_option("leaf", leaf)
+                gp = bench.make_gp(3, dtype)
+                gp.update(X_new=X, y_new=y, hyp=hyp)
+                res.append(gp.nll_batch(hyp, compute_grad=True) + gp.predict(xs, separate_samples=True))
+            for a, b in zip(res[0], res[1]):
+                assert np.array_equal(a, b)
+    finally:
+        bench.CONFIGS[3] = bench_cfg
+        ctx.set_option("leaf", 5)
