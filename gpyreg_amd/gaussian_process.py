@@ -191,62 +191,54 @@ class GP:
 
     def _plugin_values(self, hyp: np.ndarray, grad: bool):
         """Evaluate the O(N*D) boundary plugins for every sample
-        (gaussian_process.py:2371-2400): m (S,N), sn2 (S,N|1), dm, dsn2."""
-        cov_N, noise_N, mean_N = self._counts()
-        S = hyp.shape[0]
-        N = self.X.shape[0]
-        fast = self._plugin_values_builtin(hyp, grad)
-        if fast is not None:
-            return fast
-        m = np.empty((S, N))
-        sn2_rows, dm_rows, dsn2_rows = [], [], []
-        vec = False
-        for s in range(S):
-            h_noise = hyp[s, cov_N:cov_N + noise_N]
-            h_mean = hyp[s, cov_N + noise_N:cov_N + noise_N + mean_N]
-            if grad:
-                sn2, dsn2 = self.noise.compute(h_noise, self.X, self.y, self.s2, compute_grad=True)
-                ms, dm = self.mean.compute(h_mean, self.X, compute_grad=True)
-                if mean_N > 0:
-                    dm_rows.append(np.asarray(dm, dtype=float).reshape(N, mean_N))
-                if noise_N > 0:
-                    dsn2_rows.append(np.asarray(dsn2, dtype=float))
-            else:
-                sn2 = self.noise.compute(h_noise, self.X, self.y, self.s2)
-                ms = self.mean.compute(h_mean, self.X)
-            m[s] = np.reshape(ms, (-1,))
-            vec = not np.isscalar(sn2)
-            sn2_rows.append(np.ravel(sn2) if vec else np.array([float(sn2)]))
-        out = {"m": m, "sn2": np.stack(sn2_rows), "vec": vec}
-        out["dm"] = np.stack(dm_rows) if (grad and mean_N > 0) else None
-        out["dsn2"] = np.stack(dsn2_rows) if (grad and noise_N > 0) else None
-        return out
+        (gaussian_process.py:2371-2400): m (S,N), sn2 (S,N|1), dm (S,N,mean_N), dsn2 (S,N|1,noise_N).
 
-    def _plugin_values_builtin(self, hyp, grad):
-        """The same values for the stock ConstantMean / ZeroMean + constant GaussianNoise without a
-        Python loop over samples (the design stage of ``fit`` evaluates 1024 hyperparameter vectors
-        at once).  Exact types only: subclasses and other plugins take the generic per-sample path."""
-        from .mean_functions import ConstantMean, ZeroMean
+        The stock plugins evaluate all rows in one NumPy pass (their ``values``; the design stage of
+        ``fit`` hands over 1024 hyperparameter vectors at once).  Exact types only: a subclass or any other
+        object with the reference's protocol is called once per sample through its own ``compute``."""
+        from .mean_functions import ConstantMean, NegativeQuadratic, ZeroMean
         from .noise_functions import GaussianNoise
 
-        if type(self.noise) is not GaussianNoise or type(self.mean) not in (ConstantMean, ZeroMean):
-            return None
-        p = self.noise.parameters
-        if not (p[0] == 1 and p[1] == 0 and p[2] == 0):
-            return None
         cov_N, noise_N, mean_N = self._counts()
         S, N = hyp.shape[0], self.X.shape[0]
-        sn2 = np.exp(2 * hyp[:, cov_N:cov_N + 1])  # noise_functions.py:253
-        if mean_N == 1:
-            m = hyp[:, cov_N + noise_N:cov_N + noise_N + 1] * np.ones((1, N))
+        h_noise = hyp[:, cov_N:cov_N + noise_N]
+        h_mean = hyp[:, cov_N + noise_N:cov_N + noise_N + mean_N]
+        dm = dsn2 = None
+        if type(self.mean) in (ZeroMean, ConstantMean, NegativeQuadratic):
+            m = self.mean.values(h_mean, self.X, grad)
+            if grad:
+                m, dm = m
         else:
-            m = np.zeros((S, N))
-        out = {"m": m, "sn2": sn2, "vec": False, "dm": None, "dsn2": None}
-        if grad:
-            out["dsn2"] = (2 * sn2)[:, :, None]  # (S, 1, 1)
-            if mean_N == 1:
-                out["dm"] = np.ones((S, N, 1))
-        return out
+            m, dm_rows = np.empty((S, N)), []
+            for s in range(S):
+                r = self.mean.compute(h_mean[s], self.X, compute_grad=grad)
+                if grad:
+                    r, d = r
+                    if mean_N > 0:
+                        dm_rows.append(np.asarray(d, dtype=float).reshape(N, mean_N))
+                m[s] = np.reshape(r, (-1,))
+            dm = np.stack(dm_rows) if dm_rows else None
+        if type(self.noise) is GaussianNoise:
+            sn2 = self.noise.values(h_noise, self.X, self.y, self.s2, grad)
+            if grad:
+                sn2, dsn2 = sn2
+            vec = self.noise.per_point(self.y, self.s2)
+        else:
+            sn2_rows, dsn2_rows, vec = [], [], False
+            for s in range(S):
+                r = self.noise.compute(h_noise[s], self.X, self.y, self.s2, compute_grad=grad)
+                if grad:
+                    r, d = r
+                    dsn2_rows.append(np.asarray(d, dtype=float))
+                vec = not np.isscalar(r)
+                sn2_rows.append(np.ravel(r) if vec else np.array([float(r)]))
+            sn2 = np.stack(sn2_rows)
+            dsn2 = np.stack(dsn2_rows) if dsn2_rows else None
+        if dsn2 is not None and not vec:
+            dsn2 = dsn2[:, :1, :]  # a single noise value: the core reads ONE gradient row per sample (:2491-2498)
+        return {"m": m, "sn2": sn2, "vec": vec,
+                "dm": dm if (grad and mean_N > 0) else None,
+                "dsn2": dsn2 if (grad and noise_N > 0) else None}
 
     def _kid(self):
         return self.covariance._gpc_kernel_id, self.covariance._gpc_degree

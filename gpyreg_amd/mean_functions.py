@@ -1,153 +1,133 @@
-"""Mean-function plugins (reference: gpyreg/mean_functions.py).
+"""Mean-function plugins of the GP (the reference's ``gpyreg.mean_functions``: ZeroMean :6-131,
+ConstantMean :134-260, NegativeQuadratic :263-397, recommended bounds :400-459).
 
-These are the O(N*D) boundary plugins of the hot path: they are
-evaluated on the host and their values (m, dm) are handed to the device core, which
-is what the reference's GP.__core_computation does with them
-(gaussian_process.py:2379-2387).  Same names, shapes and error messages.
+Boundary plugins of the hot path: O(N*D) host arithmetic whose results -- the
+mean vector m and its gradient dm -- are inputs of the device core, exactly where the reference's
+``GP.__core_computation`` evaluates them (gaussian_process.py:2379-2387).
+
+Each class is described by a LAYOUT (named hyperparameter blocks) and evaluated for MANY
+hyperparameter vectors at once (``values``: every row of a (S, mean_N) array in one NumPy pass --
+what ``GP.nll_batch`` needs for a design of 1024 rows); the reference's one-vector ``compute`` is
+the S = 1 case of it.  Names, shapes, return conventions (``ZeroMean`` returns ``dm = []``) and
+error messages are the reference's, and the arithmetic is ordered so that values are bit-identical
+(tests/test_abi_cpu.py checks ``array_equal`` against reference-pinned values).
 """
 
 import numpy as np
 
 
-def _check(hyp, mean_N, last_line_joined=False):
-    if hyp.size != mean_N:
-        raise ValueError(
-            f"Expected {mean_N} mean function hyperparameters, "
-            f"{hyp.size} passed instead."
-        )
-    if hyp.ndim != 1:
-        raise ValueError(
-            "Mean function output is available only for "
-            "one-sample hyperparameter inputs."
-        )
+class _Mean:
+    """Plumbing shared by the mean functions: hyperparameter layout, argument checks, the
+    one-vector ``compute`` on top of the batched ``values``, and the recommended-bounds record
+    assembled from one row of (LB, UB, PLB, PUB, x0) per hyperparameter block."""
 
+    @classmethod
+    def layout(cls, D: int):
+        """[(block name, width), ...] in hyperparameter order."""
+        raise NotImplementedError
 
-class ZeroMean:
-    """m(x) = 0 (reference :6-131)."""
+    @classmethod
+    def hyperparameter_count(cls, D: int) -> int:
+        return sum(width for _, width in cls.layout(D))
 
-    def __init__(self):
-        pass
+    @classmethod
+    def hyperparameter_info(cls, D: int):
+        return list(cls.layout(D))
 
-    @staticmethod
-    def hyperparameter_count(_):
-        return 0
+    def values(self, hyp_rows: np.ndarray, X: np.ndarray, compute_grad: bool = False):
+        """m (S, N) and, with ``compute_grad``, dm (S, N, mean_N) for the rows of ``hyp_rows`` (S, mean_N)."""
+        raise NotImplementedError
 
-    @staticmethod
-    def hyperparameter_info(_):
+    def compute(self, hyp: np.ndarray, X: np.ndarray, compute_grad: bool = False):
+        """The reference's call: one hyperparameter vector -> m (N,) [, dm (N, mean_N)]."""
+        want = self.hyperparameter_count(X.shape[1])
+        if hyp.size != want:
+            raise ValueError(f"Expected {want} mean function hyperparameters, {hyp.size} passed instead.")
+        if hyp.ndim != 1:
+            raise ValueError("Mean function output is available only for one-sample hyperparameter inputs.")
+        if not compute_grad:
+            return self.values(hyp[None, :], X)[0]
+        m, dm = self.values(hyp[None, :], X, True)
+        return m[0], (dm[0] if want else [])
+
+    def _bound_rows(self, X: np.ndarray, y: np.ndarray):
+        """One (LB, UB, PLB, PUB, x0) tuple per block of ``layout``; x0 = None: midpoint of the plausible box."""
         return []
 
     def get_bounds_info(self, X: np.ndarray, y: np.ndarray):
-        return _bounds_info_helper(self.hyperparameter_count(X.shape[1]), X, y, 0)
+        if np.size(y) <= 1:  # no observations yet: a unit range
+            y = np.array([0, 1])
+        keys = ("LB", "UB", "PLB", "PUB", "x0")
+        cols = {k: [] for k in keys}
+        for (_, width), row in zip(self.layout(X.shape[1]), self._bound_rows(X, y)):
+            for k, v in zip(keys, row):
+                cols[k].append(np.full((width,), np.nan if v is None else v, dtype=float))
+        out = {k: (np.concatenate(v) if v else np.zeros((0,))) for k, v in cols.items()}
+        open_x0 = np.isnan(out["x0"])
+        out["x0"][open_x0] = 0.5 * (out["PLB"][open_x0] + out["PUB"][open_x0])
+        return out
 
-    def compute(self, hyp: np.ndarray, X: np.ndarray, compute_grad: bool = False):
-        N, D = X.shape
-        _check(hyp, self.hyperparameter_count(D))
-        m = np.zeros((N,))
-        if compute_grad:
-            return m, []
-        return m
+
+class ZeroMean(_Mean):
+    """m(x) = 0: no hyperparameters."""
+
+    @classmethod
+    def layout(cls, D):
+        return []
+
+    def values(self, hyp_rows, X, compute_grad=False):
+        m = np.zeros((hyp_rows.shape[0], X.shape[0]))
+        return (m, np.zeros(m.shape + (0,))) if compute_grad else m
 
 
-class ConstantMean:
-    """m(x) = m0 (reference :134-260)."""
+class ConstantMean(_Mean):
+    """m(x) = m0."""
 
-    def __init__(self):
-        pass
-
-    @staticmethod
-    def hyperparameter_count(_):
-        return 1
-
-    @staticmethod
-    def hyperparameter_info(_):
+    @classmethod
+    def layout(cls, D):
         return [("mean_const", 1)]
 
-    def get_bounds_info(self, X: np.ndarray, y: np.ndarray):
-        return _bounds_info_helper(self.hyperparameter_count(X.shape[1]), X, y, 1)
+    def values(self, hyp_rows, X, compute_grad=False):
+        N = X.shape[0]
+        m = hyp_rows[:, 0:1] * np.ones((1, N))
+        return (m, np.ones(m.shape + (1,))) if compute_grad else m
 
-    def compute(self, hyp: np.ndarray, X: np.ndarray, compute_grad: bool = False):
-        N, D = X.shape
-        _check(hyp, self.hyperparameter_count(D))
-        m = hyp[0] * np.ones((N,))
-        if compute_grad:
-            return m, np.ones((N, 1))
-        return m
+    def _bound_rows(self, X, y):
+        lo, hi = np.min(y), np.max(y)
+        span = hi - lo
+        return [(lo - 0.5 * span, hi + 0.5 * span, np.quantile(y, 0.1), np.quantile(y, 0.9), np.median(y))]
 
 
-class NegativeQuadratic:
-    """m(x) = m0 - 1/2 sum(((x - xm)/omega)^2) (reference :263-397)."""
+class NegativeQuadratic(_Mean):
+    """m(x) = m0 - 1/2 sum_d ((x_d - xm_d) / omega_d)^2, hyperparameters [m0 | xm (D) | log omega (D)]."""
 
-    def __init__(self):
-        pass
-
-    @staticmethod
-    def hyperparameter_count(D: int):
-        return 1 + 2 * D
-
-    @staticmethod
-    def hyperparameter_info(D: int):
+    @classmethod
+    def layout(cls, D):
         return [("mean_const", 1), ("mean_location", D), ("mean_log_scale", D)]
 
-    def get_bounds_info(self, X: np.ndarray, y: np.ndarray):
-        return _bounds_info_helper(self.hyperparameter_count(X.shape[1]), X, y, 2)
+    def values(self, hyp_rows, X, compute_grad=False):
+        D = X.shape[1]
+        centre = hyp_rows[:, None, 1:1 + D]                  # (S, 1, D)
+        omega = np.exp(hyp_rows[:, None, 1 + D:1 + 2 * D])   # (S, 1, D)
+        delta = X[None, :, :] - centre                       # (S, N, D)
+        z2 = (delta / omega) ** 2
+        m = hyp_rows[:, 0:1] - 0.5 * np.sum(z2, 2)
+        if not compute_grad:
+            return m
+        dm = np.empty(m.shape + (1 + 2 * D,))
+        dm[:, :, 0] = 1.0              # d/d m0
+        dm[:, :, 1:1 + D] = delta / omega**2   # d/d xm
+        dm[:, :, 1 + D:] = z2          # d/d log omega
+        return m, dm
 
-    def compute(self, hyp: np.ndarray, X: np.ndarray, compute_grad: bool = False):
-        N, D = X.shape
-        mean_N = self.hyperparameter_count(D)
-        _check(hyp, mean_N)
-        m_0 = hyp[0]
-        x_m = hyp[1 : 1 + D]
-        omega = np.exp(hyp[1 + D : 1 + 2 * D])
-        z_2 = ((X - x_m) / omega) ** 2
-        m = m_0 - 0.5 * np.sum(z_2, 1)
-        if compute_grad:
-            dm = np.zeros((N, mean_N))
-            dm[:, 0] = np.ones((N,))
-            dm[:, 1 : D + 1] = (X - x_m) / omega**2
-            dm[:, D + 1 :] = z_2
-            return m, dm
-        return m
-
-
-def _bounds_info_helper(mean_N, X, y, idx):
-    """Recommended bounds (reference :400-459); idx 0 zero, 1 const, 2 negquad."""
-    _, D = X.shape
-    tol = 1e-6
-    big = np.exp(3)
-    LB = np.full((mean_N,), -np.inf)
-    UB = np.full((mean_N,), np.inf)
-    PLB = np.full((mean_N,), -np.inf)
-    PUB = np.full((mean_N,), np.inf)
-    x0 = np.full((mean_N,), np.nan)
-
-    w = np.max(X) - np.min(X)
-    if np.size(y) <= 1:
-        y = np.array([0, 1])
-    h = np.max(y) - np.min(y)
-
-    if idx == 1:
-        LB[0] = np.min(y) - 0.5 * h
-        UB[0] = np.max(y) + 0.5 * h
-        PLB[0] = np.quantile(y, 0.1)
-        PUB[0] = np.quantile(y, 0.9)
-        x0[0] = np.median(y)
-    elif idx == 2:
-        LB[0] = np.min(y)
-        UB[0] = np.max(y) + h
-        PLB[0] = np.median(y)
-        PUB[0] = np.max(y)
-        x0[0] = np.quantile(y, 0.9)
-        LB[1 : 1 + D] = np.min(X) - 0.5 * w
-        UB[1 : 1 + D] = np.max(X) + 0.5 * w
-        PLB[1 : 1 + D] = np.min(X)
-        PUB[1 : 1 + D] = np.max(X)
-        x0[1 : 1 + D] = np.median(X)
-        LB[1 + D : mean_N] = np.log(w) + np.log(tol)
-        UB[1 + D : mean_N] = np.log(w) + np.log(big)
-        PLB[1 + D : mean_N] = np.log(w) + 0.5 * np.log(tol)
-        PUB[1 + D : mean_N] = np.log(w)
-        x0[1 + D : mean_N] = np.log(np.std(X, ddof=1))
-
-    i_nan = np.isnan(x0)
-    x0[i_nan] = 0.5 * (PLB[i_nan] + PUB[i_nan])
-    return {"LB": LB, "PLB": PLB, "UB": UB, "PUB": PUB, "x0": x0}
+    def _bound_rows(self, X, y):
+        xlo, xhi = np.min(X), np.max(X)
+        ylo, yhi = np.min(y), np.max(y)
+        width, span = xhi - xlo, yhi - ylo
+        tiny, big = 1e-6, np.exp(3)
+        lw = np.log(width)
+        return [
+            (ylo, yhi + span, np.median(y), yhi, np.quantile(y, 0.9)),
+            (xlo - 0.5 * width, xhi + 0.5 * width, xlo, xhi, np.median(X)),
+            (lw + np.log(tiny), lw + np.log(big), lw + 0.5 * np.log(tiny), lw, np.log(np.std(X, ddof=1))),
+        ]

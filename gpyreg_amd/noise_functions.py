@@ -1,141 +1,132 @@
-"""Noise-function plugin (reference: gpyreg/noise_functions.py).
+"""Observation-noise plugin of the GP (the reference's ``gpyreg.noise_functions.GaussianNoise``:
+constructor :6-41, layout :43-80, recommended bounds :82-177, ``compute`` :179-283).
 
-An O(N) boundary plugin of the hot path: evaluated on the host;
-its value sn2 (scalar or per-point) and gradient dsn2 are inputs of the device core
-(gaussian_process.py:2372-2378).  The scalar-vs-array distinction of the return
-value is kept because it selects the branch at gaussian_process.py:2407/:2491.
+A boundary plugin of the hot path: O(N) host arithmetic whose results -- the
+noise variance sn2 and its gradient dsn2 -- are inputs of the device core
+(gaussian_process.py:2372-2378).  The variance is a sum of up to three TERMS, each with its own
+hyperparameters:
+
+    constant          exp(2 h)                          1 hyperparameter   (absent: eps, no hyperparameter)
+    provided          s2   |   exp(h) * s2              0 | 1              (the caller's per-point estimates)
+    rectified-linear  exp(2 h_w) * max(0, h_t - y)^2    2                  (output dependent)
+
+``values`` evaluates all rows of a (S, noise_N) hyperparameter array in one NumPy pass (what
+``GP.nll_batch`` needs); the reference's one-vector ``compute`` is its S = 1 case and keeps the
+reference's return convention, which the core branches on (gaussian_process.py:2407, :2491): a
+SCALAR when no per-point term contributes, an (N, 1) array otherwise; dsn2 has one row or N rows
+accordingly.  Arithmetic is ordered so that values are bit-identical to the reference's
+(tests/test_abi_cpu.py, ``array_equal`` against reference-pinned values).
 """
 
 import numpy as np
 
 
 class GaussianNoise:
-    """Gaussian observation noise: sum of the enabled variance terms
-    (reference :6-41).  ``parameters`` = [constant, user-provided (1) / scaled (2),
-    rectified-linear output dependent]."""
+    def __init__(self, constant_add: bool = False, user_provided_add: bool = False,
+                 scale_user_provided: bool = False, rectified_linear_output_dependent_add: bool = False):
+        # the reference's encoding, read by GP.__str__ and by callers: [constant, provided (2 = scaled), rectified]
+        provided = (2 if scale_user_provided else 1) if user_provided_add else 0
+        self.parameters = np.array([1.0 if constant_add else 0.0, float(provided),
+                                    1.0 if rectified_linear_output_dependent_add else 0.0])
 
-    def __init__(
-        self,
-        constant_add: bool = False,
-        user_provided_add: bool = False,
-        scale_user_provided: bool = False,
-        rectified_linear_output_dependent_add: bool = False,
-    ):
-        self.parameters = np.zeros((3,))
-        if constant_add:
-            self.parameters[0] = 1
-        if user_provided_add:
-            self.parameters[1] = 1
-            if scale_user_provided:
-                self.parameters[1] += 1
-        if rectified_linear_output_dependent_add:
-            self.parameters[2] = 1
+    # ---- layout ---------------------------------------------------------------------------
+    def _terms(self):
+        """[(block name, width), ...] of the enabled terms that own hyperparameters."""
+        const, provided, rect = self.parameters
+        terms = []
+        if const == 1:
+            terms.append(("noise_log_scale", 1))
+        if provided == 2:
+            terms.append(("noise_provided_log_multiplier", 1))
+        if rect == 1:
+            terms.append(("noise_rectified_log_multiplier", 2))
+        return terms
 
-    def hyperparameter_count(self):
-        p = self.parameters
-        return int(p[0] == 1) + int(p[1] == 2) + 2 * int(p[2] == 1)
+    def hyperparameter_count(self) -> int:
+        return sum(width for _, width in self._terms())
 
     def hyperparameter_info(self):
-        info = []
-        if self.parameters[0] == 1:
-            info.append(("noise_log_scale", 1))
-        if self.parameters[1] == 2:
-            info.append(("noise_provided_log_multiplier", 1))
-        if self.parameters[2] == 1:
-            info.append(("noise_rectified_log_multiplier", 2))
-        return info
+        return self._terms()
 
+    # ---- recommended bounds ---------------------------------------------------------------
     def get_bounds_info(self, X: np.ndarray, y: np.ndarray):
-        """Recommended bounds (reference :82-177)."""
-        _, D = X.shape
-        noise_N = self.hyperparameter_count()
-        tol = 1e-6
-        LB = np.full((noise_N,), -np.inf)
-        UB = np.full((noise_N,), np.inf)
-        PLB = np.full((noise_N,), -np.inf)
-        PUB = np.full((noise_N,), np.inf)
-        x0 = np.full((noise_N,), np.nan)
-        if np.size(y) <= 1:
+        D = X.shape[1]
+        if np.size(y) <= 1:  # no observations yet: a unit range
             y = np.array([0, 1])
-        height = np.max(y) - np.min(y)
+        ylo, yhi = np.min(y), np.max(y)
+        tiny = 1e-6
+        # one (LB, UB, PLB, PUB, x0) row per hyperparameter, by block
+        table = {
+            "noise_log_scale": [
+                (np.log(tiny), np.log(yhi - ylo), 0.5 * np.log(tiny), np.log(np.std(y, ddof=1)), np.log(1e-3))],
+            "noise_provided_log_multiplier": [
+                (np.log(1e-3), np.log(1e3), np.log(0.5), np.log(2), np.log(1))],
+            "noise_rectified_log_multiplier": [
+                (ylo, yhi, ylo, np.maximum(yhi - 5 * D, ylo), np.maximum(yhi - 10 * D, ylo)),  # threshold
+                (np.log(1e-3), np.log(0.1), np.log(0.01), np.log(0.1), np.log(0.1))],          # log slope
+        }
+        rows = [r for name, _ in self._terms() for r in table[name]]
+        cols = np.array(rows, dtype=float).reshape(len(rows), 5)
+        out = {k: cols[:, j].copy() for j, k in enumerate(("LB", "UB", "PLB", "PUB", "x0"))}
+        open_x0 = np.isnan(out["x0"])
+        out["x0"][open_x0] = 0.5 * (out["PLB"][open_x0] + out["PUB"][open_x0])
+        return out
 
-        i = 0
-        if self.parameters[0] == 1:
-            LB[i], UB[i] = np.log(tol), np.log(height)
-            PLB[i], PUB[i] = 0.5 * np.log(tol), np.log(np.std(y, ddof=1))
-            x0[i] = np.log(1e-3)
-            i += 1
-        if self.parameters[1] == 2:
-            LB[i], UB[i] = np.log(1e-3), np.log(1e3)
-            PLB[i], PUB[i] = np.log(0.5), np.log(2)
-            x0[i] = np.log(1)
-            i += 1
-        if self.parameters[2] == 1:
-            min_y, max_y = np.min(y), np.max(y)
-            LB[i], UB[i] = min_y, max_y
-            PLB[i], PUB[i] = min_y, np.maximum(max_y - 5 * D, min_y)
-            x0[i] = np.maximum(max_y - 10 * D, min_y)
-            i += 1
-            LB[i], UB[i] = np.log(1e-3), np.log(0.1)
-            PLB[i], PUB[i] = np.log(0.01), np.log(0.1)
-            x0[i] = np.log(0.1)
-            i += 1
+    # ---- values ---------------------------------------------------------------------------
+    def per_point(self, y, s2) -> bool:
+        """True when sn2 comes out as one value per observation (a provided or an output-dependent term
+        is enabled AND its data are there), False when it is a single number."""
+        _, provided, rect = self.parameters
+        return (provided >= 1 and s2 is not None and not np.isscalar(s2)) or (rect == 1 and y is not None)
 
-        i_nan = np.isnan(x0)
-        x0[i_nan] = 0.5 * (PLB[i_nan] + PUB[i_nan])
-        return {"LB": LB, "PLB": PLB, "PUB": PUB, "UB": UB, "x0": x0}
-
-    def compute(self, hyp, X, y, s2=None, compute_grad: bool = False):
-        """sn2 (scalar when there is no per-point term, else (N,1)) and dsn2
-        ((1|N), noise_N) -- reference :179-283."""
-        N, _ = X.shape
+    def values(self, hyp_rows: np.ndarray, X: np.ndarray, y, s2=None, compute_grad: bool = False):
+        """sn2 for every row of ``hyp_rows`` (S, noise_N): (S, N) when ``per_point(y, s2)`` else (S, 1);
+        with ``compute_grad`` also dsn2 (S, R, noise_N), R = N when any per-point term is ENABLED
+        (reference :243-246: even if its data are absent), else 1."""
+        S, N = hyp_rows.shape[0], X.shape[0]
+        const, provided, rect = self.parameters
         noise_N = self.hyperparameter_count()
-        if hyp.size != noise_N:
-            raise ValueError(
-                f"Expected {noise_N} noise function hyperparameters, "
-                f"{hyp.size} passed instead."
-            )
-        if hyp.ndim != 1:
-            raise ValueError(
-                "Noise function output is available only for "
-                "one-sample hyperparameter inputs."
-            )
-        p = self.parameters
-        dsn2 = None
-        if compute_grad:
-            rows = N if any(x > 0 for x in p[1:]) else 1
-            dsn2 = np.zeros((rows, noise_N))
-
-        i = 0
-        if p[0] == 0:
-            sn2 = np.spacing(1.0)
+        wide = self.per_point(y, s2)
+        grad = np.zeros((S, N if (provided > 0 or rect > 0) else 1, noise_N)) if compute_grad else None
+        col = 0
+        if const == 1:
+            sn2 = np.exp(2 * hyp_rows[:, col:col + 1])  # (S, 1)
+            if compute_grad:
+                grad[:, :, col] = 2 * sn2
+            col += 1
         else:
-            sn2 = np.exp(2 * hyp[i])
+            sn2 = np.full((S, 1), np.spacing(1.0))
+        given = 0 if s2 is None else (s2 if np.isscalar(s2) else np.reshape(s2, (1, N)))
+        if provided == 1:
+            sn2 = sn2 + given
+        elif provided == 2:
+            scaled = np.exp(hyp_rows[:, col:col + 1]) * given
+            sn2 = sn2 + scaled
             if compute_grad:
-                dsn2[:, i] = 2 * sn2
-            i += 1
-
-        if s2 is None:
-            s2 = 0
-        if p[1] == 1:
-            sn2 = sn2 + s2
-        elif p[1] == 2:
-            sn2 = sn2 + np.exp(hyp[i]) * s2
-            if compute_grad:
-                dsn2[:, i : i + 1] = np.exp(hyp[i]) * s2
-            i += 1
-
-        if p[2] == 1:
+                grad[:, :, col] = scaled
+            col += 1
+        if rect == 1:
             if y is not None:
-                y_tresh = hyp[i]
-                w2 = np.exp(2 * hyp[i + 1])
-                zz = np.maximum(0, y_tresh - y)
-                sn2 = sn2 + w2 * zz**2
+                threshold = hyp_rows[:, col:col + 1]
+                w2 = np.exp(2 * hyp_rows[:, col + 1:col + 2])
+                gap = threshold - np.reshape(y, (1, N))
+                below = np.maximum(0, gap)
+                sn2 = sn2 + w2 * below**2
                 if compute_grad:
-                    dsn2[:, i : i + 1] = 2 * w2 * (y_tresh - y) * (zz > 0)
-                    dsn2[:, i + 1 : i + 2] = 2 * w2 * zz**2
-            i += 2
+                    grad[:, :, col] = 2 * w2 * gap * (below > 0)
+                    grad[:, :, col + 1] = 2 * w2 * below**2
+            col += 2
+        assert sn2.shape == (S, N if wide else 1)
+        return (sn2, grad) if compute_grad else sn2
 
-        if compute_grad:
-            return sn2, dsn2
-        return sn2
+    def compute(self, hyp: np.ndarray, X: np.ndarray, y, s2=None, compute_grad: bool = False):
+        """The reference's call: one hyperparameter vector -> sn2 (scalar | (N, 1)) [, dsn2 ((1 | N), noise_N)]."""
+        want = self.hyperparameter_count()
+        if hyp.size != want:
+            raise ValueError(f"Expected {want} noise function hyperparameters, {hyp.size} passed instead.")
+        if hyp.ndim != 1:
+            raise ValueError("Noise function output is available only for one-sample hyperparameter inputs.")
+        out = self.values(hyp[None, :], X, y, s2, compute_grad)
+        sn2 = out[0] if compute_grad else out
+        sn2 = sn2[0].reshape(-1, 1) if self.per_point(y, s2) else sn2[0, 0]
+        return (sn2, out[1][0]) if compute_grad else sn2
