@@ -159,7 +159,11 @@ def cpu_baseline(cfg_idx, gpu_nlz0=None, gpu_dnlz0=None):
     if gpu_nlz0 is not None:
         out["nlz_rel_err"] = float(abs(gpu_nlz0 - nlz) / max(1.0, abs(nlz)))
     if gpu_dnlz0 is not None:
-        out["grad_rel_err"] = float((np.abs(gpu_dnlz0 - dnlz) / np.maximum(np.abs(dnlz), np.abs(dnlz).max())).max())
+        # per component, relative to that component (floor: 1e-3 of the largest one, below which a component is a
+        # cancellation of terms a thousand times its size); and the looser figure relative to the largest component
+        err = np.abs(gpu_dnlz0 - dnlz)
+        out["grad_rel_err"] = float((err / np.maximum(np.abs(dnlz), 1e-3 * np.abs(dnlz).max())).max())
+        out["grad_rel_err_vs_largest"] = float(err.max() / np.abs(dnlz).max())
     return out
 
 

@@ -281,7 +281,7 @@ class GP:
             return rows, info != 0
 
         if self.shard and S > 1 and _sh.active_group(self.process_group) is not None:
-            full, bad = _sh.gather_rows(S, C, local, self.process_group)
+            full, bad = _sh.gather_rows(S, C, local, self.process_group, _sh.fingerprint(hyp))
         else:
             full, bad = local(0, S)
         if np.any(bad):
@@ -875,7 +875,7 @@ class GP:
         sharded = self.shard and S > 1 and _sh.active_group(self.process_group) is not None
         try:
             if sharded:
-                full, bad = _sh.gather_rows(S, 2, local, self.process_group)
+                full, bad = _sh.gather_rows(S, 2, local, self.process_group, _sh.fingerprint(hyp))
             else:
                 full, bad = local(0, S)
         except Exception:
@@ -904,13 +904,15 @@ class GP:
         lo, hi, _ = self._post_range
         return list(self.posteriors[lo:hi]), lo
 
-    def _gather_samples(self, local_cols):
-        """(R, S_local) per-sample columns of this rank -> (R, S) on every rank (no-op unless sharded)."""
+    def _gather_samples(self, local_cols, *args):
+        """(R, S_local) per-sample columns of this rank -> (R, S) on every rank (no-op unless sharded).
+        ``args``: the caller's arguments every rank must have passed identically (checked in the exchange)."""
         if self._post_range is None:
             return local_cols
         lo, hi, S = self._post_range
         R = local_cols.shape[0]
-        full, _ = _sh.gather_rows(S, R, lambda a, b: (local_cols.T, np.zeros(b - a, bool)), self.process_group)
+        full, _ = _sh.gather_rows(S, R, lambda a, b: (local_cols.T, np.zeros(b - a, bool)), self.process_group,
+                                  _sh.fingerprint(*args))
         return full.T.copy()
 
     def _drop_handle(self):
@@ -965,7 +967,7 @@ class GP:
                 fmu, fq, _ = self._post_handle.predict_K(Ks)
                 fs2 = kss + fq
             if self._post_range is not None:  # each rank predicted its block of samples: one all-gather
-                both = self._gather_samples(np.concatenate([fmu, fs2], axis=0))
+                both = self._gather_samples(np.concatenate([fmu, fs2], axis=0), x_star)
                 fmu, fs2 = both[:N_star], both[N_star:]
         y_s2 = np.zeros((N_star, s_N)) if (return_lpd or add_noise) else None
         lpd = np.zeros((N_star, s_N)) if (return_lpd and separate_samples) else None
@@ -1033,7 +1035,7 @@ class GP:
                 Kss = np.stack([self.covariance.compute(p.hyp[0:cov_N], x_star) for p in local_posts])
                 fmu, _, fcov = self._post_handle.predict_K(Ks, Kss, want_var=False)
             if self._post_range is not None:
-                both = self._gather_samples(np.concatenate([fmu, fcov.reshape(fcov.shape[0], -1).T], axis=0))
+                both = self._gather_samples(np.concatenate([fmu, fcov.reshape(fcov.shape[0], -1).T], axis=0), x_star)
                 fmu, fcov = both[:N_star], both[N_star:].T.reshape(-1, N_star, N_star)
         for s in range(s_N):
             hyp = self.posteriors[s].hyp
@@ -1079,7 +1081,7 @@ class GP:
         else:
             za, zkz = np.zeros((N_star, 0)), (np.zeros((N_star, 0)) if compute_var else None)
         if self._post_range is not None:
-            both = self._gather_samples(np.concatenate([za, zkz], axis=0) if compute_var else za)
+            both = self._gather_samples(np.concatenate([za, zkz], axis=0) if compute_var else za, mu, sigma)
             za, zkz = both[:N_star], (both[N_star:] if compute_var else None)
         quadratic = isinstance(self.mean, NegativeQuadratic)
         F = np.zeros((N_star, N_s))

@@ -72,14 +72,33 @@ class ShardError(RuntimeError):
     """A rank failed inside a sharded evaluation (raised on EVERY rank after the exchange)."""
 
 
-def gather_rows(S: int, ncols: int, compute_local, group=None):
+def fingerprint(*arrays) -> float:
+    """CRC-32 of the bytes (and shapes) of the arguments every rank is supposed to pass identically; exact in a
+    float64, so it can ride in the status row of the exchange."""
+    import zlib
+
+    crc = 0
+    for a in arrays:
+        a = np.ascontiguousarray(a)
+        crc = zlib.crc32(repr((a.shape, a.dtype.str)).encode(), crc)
+        crc = zlib.crc32(a.tobytes(), crc)
+    return float(crc)
+
+
+def gather_rows(S: int, ncols: int, compute_local, group=None, token: float = 0.0):
     """Run ``compute_local(lo, hi) -> (rows (hi-lo, ncols), bad (hi-lo,) bool)`` on this rank's block
     and return the full ``(S, ncols)`` array and the full ``bad`` mask on every rank.
 
     A rank whose block raises does NOT leave the others waiting in the collective: the exception is
-    caught, the rank still enters the all-gather with a status column, and every rank raises
+    caught, the rank still enters the exchange with a status row, and every rank raises
     ``ShardError`` afterwards (a non-positive-definite sample on one shard is an expected event
-    during fitting; it must not become a hang)."""
+    during fitting; it must not become a hang).
+
+    The ranks must have been called with the SAME batch.  The status row (exchanged FIRST, fixed shape)
+    carries S, ncols and ``token`` -- the caller's ``fingerprint`` of the full argument arrays: if they
+    differ between ranks (unsynchronised RNG seeds in ``fit``, a speculative batch of another length)
+    every rank raises ``ShardError`` before the data exchange, whose buffer shapes would disagree --
+    instead of silently stitching together rows of different batches."""
     rw = active_group(group)
     if rw is None:
         rows, bad = compute_local(0, S)
@@ -95,18 +114,22 @@ def gather_rows(S: int, ncols: int, compute_local, group=None):
             local[:, ncols] = np.asarray(bad, dtype=float)
     except Exception as e:  # noqa: BLE001 - exchanged, then raised on every rank
         err = e
-        local[:, :ncols] = 0.0
-        local[:, ncols] = 2.0
-    # a rank with an empty block that failed still has to be heard: one extra status row per rank
-    flag = np.zeros((1, ncols + 1))
-    flag[0, ncols] = 2.0 if err is not None else 0.0
-    full = _all_gather_rows(local, S, group)
-    flags = _all_gather_rows(flag, world, group)
+        local[:] = 0.0
+    # one status row per rank: [S, ncols, fingerprint of the arguments, failed]
+    status = _all_gather_rows(np.array([[float(S), float(ncols), float(token), 0.0 if err is None else 1.0]]),
+                              world, group)
+    if np.any(status[:, :3] != status[0, :3]):
+        detail = ", ".join(f"rank {r}: S={int(status[r, 0])} cols={int(status[r, 1])} crc={int(status[r, 2]):08x}"
+                           for r in range(world))
+        raise ShardError(
+            "the ranks of a sharded evaluation were called with different batches (" + detail + "). Every rank "
+            "must pass the same hyperparameter rows: seed NumPy's global RNG identically on all ranks before "
+            "GP.fit, or set gp.shard = False to keep this GP rank-local") from err
     if err is not None:
         raise ShardError(f"rank {rank}: {type(err).__name__}: {err}") from err
-    if np.any(flags[:, ncols] == 2.0) or np.any(full[:, ncols] == 2.0):
-        failed = [r for r in range(world) if flags[r, ncols] == 2.0]
-        raise ShardError(f"sharded evaluation failed on rank(s) {failed}")
+    if np.any(status[:, 3] != 0.0):
+        raise ShardError(f"sharded evaluation failed on rank(s) {[r for r in range(world) if status[r, 3] != 0.0]}")
+    full = _all_gather_rows(local, S, group)
     return full[:, :ncols].copy(), full[:, ncols] != 0.0
 
 

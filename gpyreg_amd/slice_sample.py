@@ -104,9 +104,10 @@ class SliceSampler:
                     # an array of values, or a callable row -> value (the host-side part of the target, e.g. the
                     # log prior, is then only evaluated for the rows the sequential procedure would have reached)
                     f = self.log_f_batch(pts[inside])
-                except Exception:
-                    # a proposal the sequential procedure might never have reached failed (e.g. a matrix that
-                    # stays non-positive-definite): hand the rest of this coordinate to the sequential loop
+                except np.linalg.LinAlgError:
+                    # a proposal the sequential procedure might never have reached is numerically infeasible (its
+                    # matrix stays non-positive-definite): hand the rest of this coordinate to the sequential loop.
+                    # Anything else -- a HIP error out of the C ABI, a ShardError, a bug in a user kernel -- propagates
                     np.random.set_state(state)
                     x_l[dd], x_r[dd] = lo, hi
                     return None, None, None, shrink

@@ -141,6 +141,22 @@ def _err_worker(rank, world, port, q):
         # (3) more ranks than samples: rank 1 has an empty block and still takes part
         rows, bad = sharding.gather_rows(1, 1, lambda lo, hi: (np.full((hi - lo, 1), 7.0), np.zeros(hi - lo, bool)))
         res.append(rows.ravel().tolist())
+        # (4) unsynchronised callers: each rank drew its batch from its own RNG (different seeds), and (5) batches of
+        # different LENGTH (the data exchange would have mismatched buffer shapes): ShardError on every rank BEFORE
+        # the data exchange, and the group stays usable (6)
+        mine = np.random.default_rng(100 + rank).standard_normal((5, 3))
+        ident = lambda lo, hi: (mine[lo:hi], np.zeros(hi - lo, bool))
+        for S_r, tok in ((5, sharding.fingerprint(mine)), (5 + rank, sharding.fingerprint(np.zeros(3)))):
+            try:
+                sharding.gather_rows(S_r, 3, (lambda lo, hi: (np.zeros((hi - lo, 3)), np.zeros(hi - lo, bool)))
+                                     if S_r != 5 else ident, token=tok)
+                res.append("no error")
+            except sharding.ShardError as e:
+                res.append("different batches" in str(e))
+        same = np.random.default_rng(7).standard_normal((5, 3))
+        rows, _ = sharding.gather_rows(5, 3, lambda lo, hi: (same[lo:hi], np.zeros(hi - lo, bool)),
+                                       token=sharding.fingerprint(same))
+        res.append(bool(np.array_equal(rows, same)))
         q.put((rank, res))
     finally:
         dist.destroy_process_group()
@@ -163,3 +179,4 @@ def test_a_failing_shard_raises_on_every_rank_instead_of_hanging():
         assert res[rank][0] == "ShardError"
         assert res[rank][1] == ([0.0, 1.0, 2.0, 3.0, 4.0], [False, False, False, False, True])
         assert res[rank][2] == [7.0]
+        assert res[rank][3:] == [True, True, True]
