@@ -280,24 +280,20 @@ __global__ __launch_bounds__(256) void build_kernel(CovDesc cd, const double* __
 }
 
 // The tail of the build (tiles tile0 .. ntiles-1 of every sample) as a persistent launch that stays off the
-// same reserved CUs as a deferred GEMM (gemm.h: blocks that land on one return at once): it runs on a side
+// same reserved CUs as a deferred GEMM (common.h: cu_reserve_bail; blocks that land on one return at once): it runs on a side
 // stream UNDER the factorization of the first rows, whose leaves need whole empty CUs.  ctr: zeroed counter.
 template <typename T, int KIND, int DEG>
 __global__ __launch_bounds__(256) void build_persist_kernel(CovDesc cd, const double* __restrict__ Xs_all,
                                                             const double* __restrict__ sp_all,
                                                             const double* __restrict__ dvec_all, int n, int npad,
                                                             T* __restrict__ A_all, long long sA, int lda, int tile0,
-                                                            int ntiles, int batch, int reserve, int* ctr) {
+                                                            int ntiles, int batch,
+                                                            const unsigned short* __restrict__ reserve, int* ctr) {
   __shared__ double xi[CT][DCH + 1];
   __shared__ double xj[CT][DCH + 1];
   __shared__ int next;
-  if (reserve) {
-    unsigned hw;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    const unsigned cu = (hw >> 8) & 0xf, se = (hw >> 13) & 0x7;
-    const unsigned idx = (se & 1) ? cu - 1 : cu;
-    if (reserve == 2 ? (idx == 7 && (se & 1) == 0) : idx + (unsigned)(reserve / 4) >= 8u) return;
-  }
+  // ctr: a zeroed group of CTR_STRIDE counters; [0] is the tile queue
+  if (reserve && cu_reserve_bail(reserve, ctr)) return;
   const int total = (ntiles - tile0) * batch;
   for (;;) {
     if (threadIdx.x == 0) next = atomicAdd(ctr, 1);

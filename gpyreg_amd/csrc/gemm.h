@@ -66,7 +66,7 @@ struct GemmArgs {
   int klo, khi, lower_only;
   int tiles_m, tiles_n;
   int flags = 0;       // GPC_GEMM_FLAGS: 8 = XCD-affine tile queues in persistent launches
-  int reserve = 0;     // persistent launches: CUs per XCD this launch stays off (0, 2 or 4), see gemm_persist_kernel
+  const unsigned short* rsv = nullptr;  // persistent launches: table of the CUs this launch stays off (cu_reserve below)
   int* ctr = nullptr;  // persistent launches: zeroed device counters the blocks draw tiles from
   int ntiles = 0, batch = 0;
 };
@@ -454,24 +454,11 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_dual_kernel(GemmArgs g1,
 // others when its own is empty.  Blocks that share an L2 then work on tiles of the same
 // sample, consecutive tiles of a sample share an operand panel, and the panel is read
 // from HBM / Infinity Cache once per XCD instead of once per tile.
-constexpr int NQ = 8;
 template <typename T, bool AKM, bool BKM, int BT, int NW>
 __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_persist_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) T smem[4 * opsz_of<T>(BT)];
   __shared__ int next_tile;
-  if (g.reserve) {
-    // CU reservation without CU-masked queues: a block that finds itself on a reserved CU (the last CU of
-    // shader engines 0 and 2 of its XCD; with reserve = 4 also of engines 1 and 3) returns at once.  The grid is
-    // oversized by the caller, the surplus drains through the reserved CUs in microseconds, and those CUs
-    // stay EMPTY for the whole launch: the latency-bound kernels of another stream (128 x 128 leaves,
-    // deep-level products) run there at full speed while this launch streams on the other CUs.
-    unsigned hw;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    const unsigned cu = (hw >> 8) & 0xf, se = (hw >> 13) & 0x7;
-    const unsigned idx = (se & 1) ? cu - 1 : cu;  // engines 1, 3 number their CUs 1..8 (tools/cumask_probe.hip)
-    // reserve = 2: last CU of engines 0 and 2; 4: last CU of every engine; 8: last two; 12: last three
-    if (g.reserve == 2 ? (idx == 7 && (se & 1) == 0) : idx + (unsigned)(g.reserve / 4) >= 8u) return;
-  }
+  if (g.rsv && cu_reserve_bail(g.rsv, g.ctr)) return;
   if (!(g.flags & 8)) {
     const int total = g.ntiles * g.batch;
     for (;;) {
@@ -525,7 +512,7 @@ inline int g_persist_spare = 0;     // tunable: GPC_PERSIST_SPARE (block slots a
 inline int g_block_slots = 512;     // two 128-tile blocks per CU (set from the device's CU count)
 template <typename T, int BT, int NW>
 inline hipError_t launch_gemm_bt(hipStream_t st, GemmArgs g, bool akm, bool bkm, int batch, int* ctr = nullptr,
-                                 int reserve = 0) {
+                                 const unsigned short* reserve = nullptr) {
   const int tm = g.M / BT, tn = g.N / BT;
   g.tiles_m = tm;
   g.tiles_n = tn;
@@ -537,7 +524,7 @@ inline hipError_t launch_gemm_bt(hipStream_t st, GemmArgs g, bool akm, bool bkm,
   g.ctr = ctr;
   const unsigned dyn = 0u;
   const int cap = g_block_slots - g_persist_spare;
-  g.reserve = reserve;
+  g.rsv = reserve;
   if (ctr && BT == 128 && cap > 0 && ((long long)ntiles * batch > cap || reserve)) {
     dim3 grid(reserve ? cap + 96 : cap), block(64 * NW);
     if (!akm && !bkm)
@@ -569,12 +556,12 @@ inline int g_small_launch_blocks = 1100;  // tunable: GPC_SMALL_BLOCKS
 inline bool g_dual_launch = true;         // tunable: GPC_DUAL (plan.h: syrk + U of a node in one launch)
 template <typename T>
 inline hipError_t launch_gemm(hipStream_t st, GemmArgs g, bool akm, bool bkm, int batch, int force_bt = 0,
-                             int* ctr = nullptr, int reserve = 0) {
+                             int* ctr = nullptr, const unsigned short* reserve = nullptr) {
   const int tm = g.M / TILE, tn = g.N / TILE;
   const long long blocks128 = (long long)(g.lower_only ? tm * (tm + 1) / 2 : tm * tn) * batch;
   const bool small = force_bt ? (force_bt == 64) : (blocks128 < g_small_launch_blocks);
   if (small && !(reserve && ctr)) return launch_gemm_bt<T, 64, 4>(st, g, akm, bkm, batch);
-  return launch_gemm_bt<T, 128, 4>(st, g, akm, bkm, batch, ctr, ctr ? reserve : 0);
+  return launch_gemm_bt<T, 128, 4>(st, g, akm, bkm, batch, ctr, ctr ? reserve : nullptr);
 }
 
 // true when launch_gemm would run g as a plain 64-tile launch (the precondition of the dual launch)
@@ -596,7 +583,7 @@ inline hipError_t launch_gemm_dual_small(hipStream_t st, GemmArgs g1, GemmArgs g
     g.ntiles = n[i] = g.lower_only ? g.tiles_m * (g.tiles_m + 1) / 2 : g.tiles_m * g.tiles_n;
     g.batch = batch;
     g.ctr = nullptr;
-    g.reserve = 0;
+    g.rsv = nullptr;
   }
   if (n[0] + n[1] <= 0 || batch <= 0) return hipSuccess;
   hipLaunchKernelGGL((gemm_dual_kernel<T, false, false, false, true, BT, 4>), dim3(n[0] + n[1], batch), dim3(256), 0, st,

@@ -275,6 +275,16 @@ struct gpc_ctx {
   // levels when the batch is small enough for latency-bound phases to matter); GPC_DEFER_RESERVE: CUs per
   // XCD the deferred launch keeps empty (2, 4, 8, 12)
   int defer_min = -1, defer_reserve = 8;
+  // The device's own numbering of shader engines and CUs, probed at gpc_create (probe_cu_map): cu_seen[xcc * 8 + se]
+  // = bit mask of the CU_IDs workgroups were observed on.  The table of reserved CUs (rsv_tbl, same indexing; read
+  // by common.h: cu_reserve_bail) is derived from it, so nothing about the harvesting map is assumed.  cu_map_ok:
+  // the probe saw every CU the runtime reports, the same number in every engine; otherwise the deferred schedule
+  // (which needs empty CUs to pay) is off.
+  unsigned cu_seen[64] = {};
+  bool cu_map_ok = false;
+  DevBuf rsv_tbl;
+  int stable = 0;        // option: every factorization in stable mode (plan.h), not only the jitter retries
+  int check_queues = 0;  // debug option: verify after every pipeline that the tile queues of its persistent launches were drained
   hipEvent_t ev_up = nullptr, ev_done[MAXG] = {};
   int groups = 2;
   hipEvent_t ev_l0[MAXG + 1] = {}, ev_l1[MAXG + 1] = {};  // around the lauum launch of each group
@@ -387,6 +397,79 @@ struct gpc_post {
   } while (0)
 
 namespace {
+
+// Which (XCC_ID, SE_ID, CU_ID) triples does this device run workgroups on?  Enough short-lived blocks to cover every
+// CU several times over; each marks the CU it finds itself on and lingers a few microseconds so that the
+// dispatcher has to spread the grid.
+__global__ __launch_bounds__(256) void cu_probe_kernel(unsigned* __restrict__ seen, long long spin_ticks) {
+  if (threadIdx.x == 0) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    atomicOr(seen + (xcc & 7) * 8 + ((hw >> 13) & 0x7), 1u << ((hw >> 8) & 0xf));
+  }
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < spin_ticks) {
+  }
+}
+
+int probe_cu_map(gpc_ctx* c, int n_cus) {
+  HIPCHK(c, c->dbg1.ensure(64 * sizeof(unsigned)));
+  HIPCHK(c, hipMemsetAsync(c->dbg1.p, 0, 64 * sizeof(unsigned), c->st));
+  int seen_total = 0;
+  for (int attempt = 0; attempt < 3 && seen_total < n_cus; ++attempt) {
+    hipLaunchKernelGGL(cu_probe_kernel, dim3(16 * std::max(n_cus, 1)), dim3(256), 0, c->st, c->dbg1.as<unsigned>(), 500ll);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->cu_seen, c->dbg1.p, sizeof c->cu_seen, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    seen_total = 0;
+    for (unsigned m : c->cu_seen) seen_total += __builtin_popcount(m);
+  }
+  // usable for reserving CUs: every CU accounted for, and every engine that exists has the same number of them
+  int per_engine = -1, engines = 0;
+  bool uniform = true;
+  for (unsigned m : c->cu_seen) {
+    if (!m) continue;
+    ++engines;
+    const int k = __builtin_popcount(m);
+    if (per_engine < 0) per_engine = k;
+    uniform = uniform && k == per_engine;
+  }
+  c->cu_map_ok = seen_total == n_cus && uniform && engines > 0;
+  char buf[160];
+  snprintf(buf, sizeof buf, " cu_map=%s(%d CUs seen in %d engines of %d)", c->cu_map_ok ? "ok" : "UNRECOGNISED: deferred schedule off",
+           seen_total, engines, per_engine);
+  c->devinfo += buf;
+  return 0;
+}
+
+// rsv_tbl for `reserve` CUs per XCD: the highest-numbered CUs of each shader engine -- 2: one in every other engine,
+// 4: one per engine, 8: two, 12: three, ...; >= 32 (test hook): every CU, which leaves the work to the one block the
+// survivor rule of cu_reserve_bail keeps.
+int build_reserve_table(gpc_ctx* c) {
+  unsigned short tbl[64] = {};
+  const int r = c->defer_reserve;
+  for (int x = 0; x < 8; ++x) {
+    int engine_no = 0;
+    for (int se = 0; se < 8; ++se) {
+      unsigned m = c->cu_seen[x * 8 + se];
+      if (!m) continue;
+      int k = r >= 32 ? 16 : (r == 2 ? (engine_no % 2 == 0 ? 1 : 0) : r / 4);
+      ++engine_no;
+      unsigned out = 0;
+      for (int cu = 15; cu >= 0 && k > 0; --cu)
+        if ((m >> cu) & 1u) {
+          out |= 1u << cu;
+          --k;
+        }
+      tbl[x * 8 + se] = (unsigned short)out;
+    }
+  }
+  HIPCHK(c, c->rsv_tbl.ensure(sizeof tbl));
+  HIPCHK(c, hipMemcpyAsync(c->rsv_tbl.p, tbl, sizeof tbl, hipMemcpyHostToDevice, c->st));
+  HIPCHK(c, hipStreamSynchronize(c->st));
+  return 0;
+}
 
 int cov_count_of(int kind, int D) {
   switch (kind) {
@@ -617,19 +700,19 @@ struct Pipe {
       // rest as a persistent, CU-reserving launch on the side stream under the first subtree (plan.h waits
       // for it before the first launch that reads rows >= 1024).
       const int head64 = 1024 / CT, ntl_head = head64 * (head64 + 1) / 2;
-      split_build = defer_node > 0 && !c->capturing && gpc::g_persist_spare >= 0 && npad >= 2048;
+      split_build = defer_node > 0 && !c->capturing && gpc::g_persist_spare >= 0 && npad >= 2048 && reserve_tbl();
       const double* dv = c->dvec.as<double>() + (size_t)off * npad;
       if (split_build) {
         GPC_COV_DISPATCH(build_kernel, T, b.cd, dim3(ntl_head, n), dim3(256), 0, st, b.cd, (const double*)xs,
                          (const double*)spb, dv, N, npad, Ac, sM, npad, 0);
         hipStream_t sd = c->sst[gidx];
-        int* bctr = c->tile_ctr.as<int>() + (size_t)gidx * gpc_ctx::CTR_PER_GROUP + gpc_ctx::CTR_PER_GROUP - 1;
-        HIPCHK(c, hipMemsetAsync(bctr, 0, sizeof(int), st));
+        int* bctr = c->tile_ctr.as<int>() + (size_t)gidx * gpc_ctx::CTR_PER_GROUP + gpc_ctx::CTR_PER_GROUP - CTR_STRIDE;
+        HIPCHK(c, hipMemsetAsync(bctr, 0, CTR_STRIDE * sizeof(int), st));
         HIPCHK(c, hipEventRecord(c->ev_bfork[gidx], st));
         HIPCHK(c, hipStreamWaitEvent(sd, c->ev_bfork[gidx], 0));
         GPC_COV_DISPATCH(build_persist_kernel, T, b.cd, dim3(4 * gpc::g_block_slots / 2 + 128), dim3(256), 0, sd, b.cd,
                          (const double*)xs, (const double*)spb, dv, N, npad, Ac, sM, npad, ntl_head, ntl, n,
-                         c->defer_reserve, bctr);
+                         reserve_tbl(), bctr);
         HIPCHK(c, hipEventRecord(c->ev_btail[gidx], sd));
       } else {
         GPC_COV_DISPATCH(build_kernel, T, b.cd, dim3(ntl, n), dim3(256), 0, st, b.cd, (const double*)xs,
@@ -650,26 +733,28 @@ struct Pipe {
     F.logdet = d_logdet;
     F.info = d_info;
     F.nvalid = N;
+    F.stable = stable || c->stable;
     if (defer_node > 0 && !c->capturing && gpc::g_persist_spare >= 0) {
       F.side = c->sst[gidx];
       F.evs = c->dev_ev[gidx];
       F.nev = gpc_ctx::NDEV;
       F.defer_min = defer_node;
-      F.reserve = c->defer_reserve;
+      F.reserve = reserve_tbl();
     }
+    if (c->check_queues && !c->capturing) F.qlog = &qlog;
     if (split_build) {
       F.ev_tail = c->ev_btail[gidx];
       F.tail_row0 = 1024;
     }
     if (gpc::g_persist_spare >= 0) {
-      // (the last counter of the group belongs to the split build, already in flight on the side stream)
+      // (the last counters of the group belong to the split build, already in flight on the side stream)
       F.ctr = c->tile_ctr.as<int>() + (size_t)gidx * gpc_ctx::CTR_PER_GROUP;
-      F.ctr_cap = gpc_ctx::CTR_PER_GROUP - NQ;
+      F.ctr_cap = gpc_ctx::CTR_PER_GROUP - CTR_STRIDE;
       // (no launch of a small problem is persistent -- its largest, W^T W, has tm (tm + 1) / 2 tiles per sample --
       // and the zeroing would be a launch of its own on the critical path)
       const long long tmx = npad / TILE, biggest = tmx * (tmx + 1) / 2 * n;
       if (defer_node > 0 || biggest >= std::min<long long>(gpc::g_small_launch_blocks, gpc::g_block_slots - gpc::g_persist_spare))
-        HIPCHK(c, hipMemsetAsync(F.ctr, 0, (gpc_ctx::CTR_PER_GROUP - NQ) * sizeof(int), st));
+        HIPCHK(c, hipMemsetAsync(F.ctr, 0, (gpc_ctx::CTR_PER_GROUP - CTR_STRIDE) * sizeof(int), st));
       else
         F.ctr = nullptr;
     }
@@ -745,7 +830,7 @@ struct Pipe {
     hipStream_t st = c->st;
     const unsigned long long key[4] = {
         ((unsigned long long)mode << 60) | ((unsigned long long)sizeof(T) << 52) | ((unsigned long long)b.vec_noise << 48) |
-            ((unsigned long long)prescaled << 49) |
+            ((unsigned long long)prescaled << 49) | ((unsigned long long)(stable || c->stable) << 50) |
             ((unsigned long long)cnt << 24) | (unsigned long long)b.N,
         ((unsigned long long)b.cd.kind << 48) | ((unsigned long long)b.cd.degree << 40) | ((unsigned long long)b.D << 20) |
             ((unsigned long long)mean_N << 10) | (unsigned long long)noise_N,
@@ -792,10 +877,50 @@ struct Pipe {
     return 0;
   }
 
+  // the table of CUs a deferred / split launch stays off, or nullptr when the device's CU numbering was not
+  // recognised or no CU is to be reserved (the launches are then plain persistent ones)
+  const unsigned short* reserve_tbl() const {
+    return (c->cu_map_ok && c->defer_reserve > 0) ? c->rsv_tbl.as<unsigned short>() : nullptr;
+  }
+  std::vector<typename Factor<T>::QueueCheck> qlog;  // debug option check_queues
+
+  // check_queues: every tile queue of every persistent launch of the pipeline that just ran must have handed out all
+  // its tiles (a queue counter below its total = tiles nobody computed: the grid was starved)
+  int verify_queues() {
+    if (qlog.empty()) return 0;
+    std::vector<int> h((gpc_ctx::MAXG + 1) * gpc_ctx::CTR_PER_GROUP);
+    HIPCHK(c, hipMemcpy(h.data(), c->tile_ctr.p, h.size() * sizeof(int), hipMemcpyDeviceToHost));
+    for (const auto& q : qlog) {
+      const int* v = h.data() + (q.slot - c->tile_ctr.as<int>());
+      long long drawn = 0;
+      const bool affine = (gpc::g_gemm_flags & 8) != 0;
+      if (!affine) {
+        drawn = std::min<long long>(v[0], (long long)q.ntiles * q.batch);
+      } else {
+        const int nclass = q.batch >= NQ ? 1 : NQ / q.batch;
+        for (int k = 0; k < NQ; ++k) {
+          long long total;
+          if (q.batch >= NQ)
+            total = (long long)q.ntiles * ((q.batch - k + NQ - 1) / NQ);
+          else
+            total = k >= q.batch * nclass ? 0 : (q.ntiles - k / q.batch + nclass - 1) / nclass;
+          drawn += std::min<long long>(v[k], total);
+        }
+      }
+      if (drawn != (long long)q.ntiles * q.batch) {
+        qlog.clear();
+        FAIL(c, "internal error: a persistent GEMM launch ended with tiles left in its queues");
+      }
+    }
+    qlog.clear();
+    return 0;
+  }
+
   int chunk_cnt = 0;
   int chunk_s0 = 0;  // first sample (batch numbering) of the chunk being processed
   int defer_node = 0;  // plan.h: nodes at least this large run their U product on the side stream (0: none)
   bool split_build = false;
+  bool stable = false;  // plan.h: refined panel solves (jitter retries; gpc_set_option "stable")
   bool prescaled = false;  // the transfer kernel of this chunk has written the scaled inputs (run())
   int lauum_n[gpc_ctx::MAXG + 1] = {};
 
@@ -894,7 +1019,7 @@ struct Pipe {
     // N=2048 S=16 4.42 -> 4.04 ms, N=4096 S=4 8.59 -> 7.47, N=4096 S=16 21.5 -> 20.2, N=4096 S=32 39.4 -> 38.7
     // -- and cost a little beyond (N=8192 S=64: 556 -> 584 ms).  With them one sample group is better than two.
     defer_node = 0;
-    if (mode != MODE_NLL && c->defer_min != 0) {
+    if (mode != MODE_NLL && c->defer_min != 0 && (c->cu_map_ok || c->defer_min > 0)) {
       const double work = (double)cnt * std::pow((double)npad / 4096.0, 3.0);
       if (c->defer_min > 0)
         defer_node = c->defer_min;
@@ -953,6 +1078,16 @@ struct Pipe {
     memcpy(hinfo.data(), hscal.data() + 2 * (size_t)cnt, (size_t)cnt * sizeof(int));
     hc.lap("d2h+sync");
     for (int i = 0; i < cnt; ++i) b.info[s0 + i] = hinfo[i];
+    for (int i = 0; i < cnt; ++i)
+      if (hinfo[i] & LEAF_TIMEOUT) {
+        c->err = "internal error: a hand-off between the waves of a 128 x 128 leaf factorization timed out (sample " +
+                 std::to_string(s0 + i) + "); the results of this call are invalid";
+        return -3;
+      }
+    if (c->check_queues) {
+      int rc = verify_queues();
+      if (rc) return rc;
+    }
     if (kmode() && mode == MODE_GRAD)
       for (int i = 0; i < cnt; ++i)
         if (hinfo[i] == 0) {
@@ -996,7 +1131,12 @@ struct Pipe {
         fail.push_back(s);
         b.tries[s] = 1;
       }
-    while (!fail.empty() && b.tries[fail[0]] < 10) {
+    // The attempt that failed ran in fast mode (trsm as a product with an explicit inverse: not backward stable when
+    // the factor is ill-conditioned, plan.h).  The first retry repeats the SAME multiplier in stable mode -- where
+    // LAPACK, i.e. the reference, may well succeed -- and every later level (x 10 each, ten levels in all like
+    // :2413-2421) runs in stable mode too.
+    bool same_level = !(stable || c->stable);
+    while (!fail.empty() && (same_level || b.tries[fail[0]] < 10)) {
       const int nf = (int)fail.size();
       Batch sb;
       sb.S = nf;
@@ -1024,16 +1164,20 @@ struct Pipe {
       sb.init();
       for (int i = 0; i < nf; ++i) {
         const int s = fail[i];
-        b.mult[s] *= 10.0;
-        b.tries[s] += 1;
-        b.apply_mult(s);
+        if (!same_level) {
+          b.mult[s] *= 10.0;
+          b.tries[s] += 1;
+          b.apply_mult(s);
+        }
         sb.mult[i] = b.mult[s];
         sb.apply_mult(i);
       }
+      same_level = false;
       Pipe<T> q;
       q.c = c;
       q.B = &sb;
       q.mode = mode;
+      q.stable = true;
       q.A = wA;
       q.W = wW;
       q.Tm = wT;
@@ -1871,6 +2015,11 @@ int gpc_create(int device, gpc_ctx** out) {
     delete c;
     return -1;
   }
+  if (probe_cu_map(c, prop.multiProcessorCount) != 0 || build_reserve_table(c) != 0) {
+    g_create_err = "probing the CU map failed: " + c->err;
+    delete c;
+    return -1;
+  }
   if (const char* e = getenv("GPC_LEAF")) gpc::g_leaf_version = atoi(e) == 3 ? 3 : 5;
   if (const char* e = getenv("GPC_GRAPH_MAX_NPAD")) c->graph_max_npad = atoi(e);
   if (const char* e = getenv("GPC_GROUPS")) c->groups = std::max(1, std::min((int)gpc_ctx::MAXG, atoi(e)));
@@ -1889,7 +2038,7 @@ void gpc_destroy(gpc_ctx* c) {
   DevBuf* bufs[] = {&c->dX,   &c->mA,    &c->mW,  &c->mT,   &c->xs,   &c->spb,  &c->mulb, &c->divb,
                     &c->dvec, &c->rvec,  &c->zvec, &c->avec, &c->scal, &c->parts, &c->gout, &c->diagq,
                     &c->dmb,  &c->dsn2b, &c->mg,  &c->ng,   &c->ks,   &c->vb,   &c->xss,  &c->pout, &c->kss,
-                    &c->dbg1, &c->dbg2,  &c->dbg3, &c->tpart, &c->tile_ctr};
+                    &c->dbg1, &c->dbg2,  &c->dbg3, &c->tpart, &c->tile_ctr, &c->rsv_tbl};
   for (auto& g : c->graphs)
     if (g.exec) (void)hipGraphExecDestroy(g.exec);
   for (DevBuf* b : bufs) b->release();
@@ -2296,8 +2445,15 @@ int gpc_set_option(gpc_ctx* c, const char* name, int value) {
     gpc::g_leaf_version = value == 3 ? 3 : 5;
   else if (n == "defer_min")  // deferred inverse products: node size from which U runs on the side stream (0 off, -1 auto)
     c->defer_min = value;
-  else if (n == "defer_reserve")
+  else if (n == "defer_reserve") {  // CUs per XCD a deferred launch stays off (2, 4, 8, 12; >= 32: all of them, a test hook)
     c->defer_reserve = value;
+    if (build_reserve_table(c)) return -1;
+  } else if (n == "leaf_fault")  // test hook: the pipelined leaf runs with a missing wave, its hand-offs time out
+    gpc::g_leaf_fault = value != 0;
+  else if (n == "stable")  // every factorization in stable mode (refined panel solves, plan.h), not only the jitter retries
+    c->stable = value != 0;
+  else if (n == "check_queues")  // debug: verify the tile queues of persistent launches after every pipeline
+    c->check_queues = value != 0;
   else if (n == "start_mult_log10")  // test hook: first jitter multiplier 10^value
     c->start_mult = std::pow(10.0, std::max(0, std::min(9, value)));
   else if (n == "append_fail_mask")  // test hook: samples whose rank-one append is declared unstable

@@ -175,10 +175,16 @@ __device__ __forceinline__ void mma_slot(A& c, T a, T b) {
 }
 }  // namespace leaf3
 
-template <typename T, int P>
+// STABLE (the mode of the jitter retries, plan.h): the panel solve as a product with the explicit inverse W_PP has an
+// error of cond(L_PP) eps instead of eps -- on a numerically singular matrix that perturbs the trailing pivots by far
+// more than their size, and the factorization fails where a triangular solve (LAPACK) succeeds
+// (tools/jitter_model.py).  One step of refinement against the factor itself,
+//   L_iP += (A_iP - L_iP L_PP^T) W_PP^T,
+// restores the accuracy of a solve.  myL: per-wave image of L_PP, zeros above the diagonal.
+template <typename T, int P, bool STABLE>
 __device__ __forceinline__ void leaf3_panel(typename MM<T>::acc_t (&S)[2][8], T* __restrict__ colbuf,
                                             T* __restrict__ lcol, T* __restrict__ rowbuf,
-                                            T* __restrict__ urow, T* __restrict__ myW,
+                                            T* __restrict__ urow, T* __restrict__ myW, T* __restrict__ myL,
                                             T* __restrict__ Ab, int lda, int w, int lane, double& lg,
                                             int& bad) {
   using acc_t = typename MM<T>::acc_t;
@@ -215,6 +221,10 @@ __device__ __forceinline__ void leaf3_panel(typename MM<T>::acc_t (&S)[2][8], T*
   if (lq == 0) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) myW[i * LDC + l15] = wv[i];
+    if constexpr (STABLE) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) myL[l15 * LDC + c] = (c <= l15) ? d[c] : (T)0;
+    }
   }
   if (w == 0 && lq == 0) {
     T dkk = d[0];
@@ -234,6 +244,25 @@ __device__ __forceinline__ void leaf3_panel(typename MM<T>::acc_t (&S)[2][8], T*
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         c = MM<T>::mma(colbuf[(16 * i + l15) * LDC + 4 * q + lq], myW[l15 * LDC + 4 * q + lq], c);
+      if constexpr (STABLE) {
+        // rows 16 i .. 16 i + 15 of lcol / colbuf are this wave's alone in this phase: scratch for the relayouts
+        // (accumulator layout -> A-operand fragments); LDS operations of one wave complete in order
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lcol[(16 * i + MM<T>::row_of(lane, e)) * LDC + l15] = c[e];
+        __builtin_amdgcn_wave_barrier();
+        acc_t res = S[r][P];  // A_iP
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          res = MM<T>::mma(-lcol[(16 * i + l15) * LDC + 4 * q + lq], myL[l15 * LDC + 4 * q + lq], res);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) colbuf[(16 * i + MM<T>::row_of(lane, e)) * LDC + l15] = res[e];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          c = MM<T>::mma(colbuf[(16 * i + l15) * LDC + 4 * q + lq], myW[l15 * LDC + 4 * q + lq], c);
+        __builtin_amdgcn_wave_barrier();
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int row = 16 * i + MM<T>::row_of(lane, e);
@@ -291,7 +320,7 @@ __device__ __forceinline__ void leaf3_panel(typename MM<T>::acc_t (&S)[2][8], T*
 #ifndef GPC_LEAF3_WPS
 #define GPC_LEAF3_WPS 1
 #endif
-template <typename T>
+template <typename T, bool STABLE>
 __global__ __launch_bounds__(256, GPC_LEAF3_WPS) void leaf3_kernel(T* __restrict__ A, long long sA, int lda,
                                                     T* __restrict__ W, long long sW, int ldw, int off,
                                                     double* __restrict__ logdet, int* __restrict__ info,
@@ -303,6 +332,7 @@ __global__ __launch_bounds__(256, GPC_LEAF3_WPS) void leaf3_kernel(T* __restrict
   __shared__ T rowbuf[16 * LDR];
   __shared__ T urow[16 * LDR];
   __shared__ T dgW[4][16 * LDC];
+  __shared__ T dgL[STABLE ? 4 : 1][16 * LDC];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, l15 = lane & 15;
   T* Ab = A + (size_t)blockIdx.x * sA;
   T* Wb = W + (size_t)blockIdx.x * sW;
@@ -326,14 +356,14 @@ __global__ __launch_bounds__(256, GPC_LEAF3_WPS) void leaf3_kernel(T* __restrict
   double lg = 0.0;
   int bad = 0;
   // panels that start at or beyond nvalid are identity padding: L = I, W = I, already in place
-  leaf3_panel<T, 0>(S, colbuf, lcol, rowbuf, urow, dgW[w], Ab, lda, w, lane, lg, bad);
-  if (nvalid > 16) leaf3_panel<T, 1>(S, colbuf, lcol, rowbuf, urow, dgW[w], Ab, lda, w, lane, lg, bad);
-  if (nvalid > 32) leaf3_panel<T, 2>(S, colbuf, lcol, rowbuf, urow, dgW[w], Ab, lda, w, lane, lg, bad);
-  if (nvalid > 48) leaf3_panel<T, 3>(S, colbuf, lcol, rowbuf, urow, dgW[w], Ab, lda, w, lane, lg, bad);
-  if (nvalid > 64) leaf3_panel<T, 4>(S, colbuf, lcol, rowbuf, urow, dgW[w], Ab, lda, w, lane, lg, bad);
-  if (nvalid > 80) leaf3_panel<T, 5>(S, colbuf, lcol, rowbuf, urow, dgW[w], Ab, lda, w, lane, lg, bad);
-  if (nvalid > 96) leaf3_panel<T, 6>(S, colbuf, lcol, rowbuf, urow, dgW[w], Ab, lda, w, lane, lg, bad);
-  if (nvalid > 112) leaf3_panel<T, 7>(S, colbuf, lcol, rowbuf, urow, dgW[w], Ab, lda, w, lane, lg, bad);
+  leaf3_panel<T, 0, STABLE>(S, colbuf, lcol, rowbuf, urow, dgW[w], dgL[STABLE ? w : 0], Ab, lda, w, lane, lg, bad);
+  if (nvalid > 16) leaf3_panel<T, 1, STABLE>(S, colbuf, lcol, rowbuf, urow, dgW[w], dgL[STABLE ? w : 0], Ab, lda, w, lane, lg, bad);
+  if (nvalid > 32) leaf3_panel<T, 2, STABLE>(S, colbuf, lcol, rowbuf, urow, dgW[w], dgL[STABLE ? w : 0], Ab, lda, w, lane, lg, bad);
+  if (nvalid > 48) leaf3_panel<T, 3, STABLE>(S, colbuf, lcol, rowbuf, urow, dgW[w], dgL[STABLE ? w : 0], Ab, lda, w, lane, lg, bad);
+  if (nvalid > 64) leaf3_panel<T, 4, STABLE>(S, colbuf, lcol, rowbuf, urow, dgW[w], dgL[STABLE ? w : 0], Ab, lda, w, lane, lg, bad);
+  if (nvalid > 80) leaf3_panel<T, 5, STABLE>(S, colbuf, lcol, rowbuf, urow, dgW[w], dgL[STABLE ? w : 0], Ab, lda, w, lane, lg, bad);
+  if (nvalid > 96) leaf3_panel<T, 6, STABLE>(S, colbuf, lcol, rowbuf, urow, dgW[w], dgL[STABLE ? w : 0], Ab, lda, w, lane, lg, bad);
+  if (nvalid > 112) leaf3_panel<T, 7, STABLE>(S, colbuf, lcol, rowbuf, urow, dgW[w], dgL[STABLE ? w : 0], Ab, lda, w, lane, lg, bad);
 
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
@@ -345,6 +375,14 @@ __global__ __launch_bounds__(256, GPC_LEAF3_WPS) void leaf3_kernel(T* __restrict
         const int row = 16 * i + MM<T>::row_of(lane, e), col = 16 * j + l15;
         Wb[(size_t)row * ldw + col] = (j <= i) ? S[r][j][e] : (T)0;
       }
+  }
+  if constexpr (STABLE) {
+    // L11 of an enclosing node becomes a GEMM operand (plan.h, stable mode): the part of this tile above the diagonal
+    // still holds entries of the input matrix and must read as zero
+    for (int idx = t; idx < TILE * TILE; idx += 256) {
+      const int row = idx / TILE, col = idx % TILE;
+      if (col > row) Ab[(size_t)row * lda + col] = (T)0;
+    }
   }
   if (w == 0) {
     lg = wave_sum(lg);
@@ -405,15 +443,18 @@ struct Shared {
 constexpr int trow(int U, int r) { return r == 0 ? 7 - U : (r == 1 ? 2 + U : 1 - U); }
 constexpr int slot_of(int U, int i) { return trow(U, 0) == i ? 0 : (trow(U, 1) == i ? 1 : (trow(U, 2) == i ? 2 : -1)); }
 
-// Every wave reaches the end of every wait: a hand-off that never comes (a bug, not a data condition) is reported
-// as a failed pivot after ~0.1 s instead of hanging the queue.
+// Every wave reaches the end of every wait: a hand-off that never comes (a bug, not a data condition) ends the wait
+// after ~0.1 s instead of hanging the queue, and sets `tmo`.  The kernel then reports LEAF_TIMEOUT in `info` -- a code
+// of its own, which the host turns into an ERROR (gpcore.hip: Pipe::run), never into a jitter retry: the results of
+// such a leaf are garbage, not "not positive definite".  After its first time-out a wave no longer waits at all.
 template <bool SLEEP>
-__device__ __forceinline__ void wait_ge(int* f, int v, int& bad) {
+__device__ __forceinline__ void wait_ge(int* f, int v, int& tmo) {
+  if (tmo) return;
   int n = 0;
   while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < v) {
     if (SLEEP) __builtin_amdgcn_s_sleep(1);
     if (++n > (1 << 21)) {
-      bad = 1;
+      tmo = 1;
       break;
     }
   }
@@ -425,6 +466,7 @@ __device__ __forceinline__ void post(int* f, int v) {
 template <typename T, int U, int P>
 __device__ __forceinline__ void update_panel(typename MM<T>::acc_t (&S)[3][8], Shared<T>& sh, T* __restrict__ Ab,
                                              int lda, T* __restrict__ Wb, int ldw, int lane, int& bad) {
+  // (`bad` of an update wave: one of its waits timed out -- the update waves see no pivots)
   using acc_t = typename MM<T>::acc_t;
   const int l15 = lane & 15, lq = lane >> 4;
   T* lc = sh.lcol[P & 1];
@@ -668,7 +710,7 @@ __device__ __forceinline__ void update_wave(Shared<T>& sh, T* __restrict__ Ab, i
 
 template <typename T, int P>
 __device__ __forceinline__ void diag_panel(Shared<T>& sh, T* __restrict__ Ab, int lda, int lane, double& lg,
-                                           int& bad) {
+                                           int& bad, int& tmo) {
   const int l15 = lane & 15, lq = lane >> 4;
   T d[16], wv[16];
   LEAF_TS(0, P, 0);
@@ -676,7 +718,7 @@ __device__ __forceinline__ void diag_panel(Shared<T>& sh, T* __restrict__ Ab, in
 #pragma unroll
     for (int c = 0; c < 16; ++c) d[c] = Ab[(size_t)l15 * lda + c];
   } else {
-    wait_ge<false>(&sh.flagA, P + 1, bad);
+    wait_ge<false>(&sh.flagA, P + 1, tmo);
     const T* dA = sh.diagA[P & 1];
 #pragma unroll
     for (int c = 0; c < 16; ++c) d[c] = dA[l15 * LDC + c];
@@ -712,7 +754,7 @@ __device__ __forceinline__ void diag_panel(Shared<T>& sh, T* __restrict__ Ab, in
 template <typename T>
 __global__ __launch_bounds__(256, 1) void leaf5_kernel(T* __restrict__ A, long long sA, int lda, T* __restrict__ W,
                                                        long long sW, int ldw, int off, double* __restrict__ logdet,
-                                                       int* __restrict__ info, int nvalid) {
+                                                       int* __restrict__ info, int nvalid, int fault) {
   using namespace leaf5;
   __shared__ Shared<T> sh;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -731,14 +773,15 @@ __global__ __launch_bounds__(256, 1) void leaf5_kernel(T* __restrict__ A, long l
   int bad = 0;
   if (w == 0) {
     double lg = 0.0;
-    diag_panel<T, 0>(sh, Ab, lda, lane, lg, bad);
-    if (np > 1) diag_panel<T, 1>(sh, Ab, lda, lane, lg, bad);
-    if (np > 2) diag_panel<T, 2>(sh, Ab, lda, lane, lg, bad);
-    if (np > 3) diag_panel<T, 3>(sh, Ab, lda, lane, lg, bad);
-    if (np > 4) diag_panel<T, 4>(sh, Ab, lda, lane, lg, bad);
-    if (np > 5) diag_panel<T, 5>(sh, Ab, lda, lane, lg, bad);
-    if (np > 6) diag_panel<T, 6>(sh, Ab, lda, lane, lg, bad);
-    if (np > 7) diag_panel<T, 7>(sh, Ab, lda, lane, lg, bad);
+    int tmo = 0;
+    diag_panel<T, 0>(sh, Ab, lda, lane, lg, bad, tmo);
+    if (np > 1) diag_panel<T, 1>(sh, Ab, lda, lane, lg, bad, tmo);
+    if (np > 2) diag_panel<T, 2>(sh, Ab, lda, lane, lg, bad, tmo);
+    if (np > 3) diag_panel<T, 3>(sh, Ab, lda, lane, lg, bad, tmo);
+    if (np > 4) diag_panel<T, 4>(sh, Ab, lda, lane, lg, bad, tmo);
+    if (np > 5) diag_panel<T, 5>(sh, Ab, lda, lane, lg, bad, tmo);
+    if (np > 6) diag_panel<T, 6>(sh, Ab, lda, lane, lg, bad, tmo);
+    if (np > 7) diag_panel<T, 7>(sh, Ab, lda, lane, lg, bad, tmo);
     // sum(log diag L): two logarithms per lane instead of eight in a row, summed per column in panel order
     // (the order of leaf3) by the first row of 16 lanes
     __builtin_amdgcn_wave_barrier();
@@ -752,31 +795,38 @@ __global__ __launch_bounds__(256, 1) void leaf5_kernel(T* __restrict__ A, long l
     }
     lg = wave_sum(lg);
     if (lane == 0) {
+      if (tmo) atomicOr(info + blockIdx.x, LEAF_TIMEOUT);
       if (bad) atomicCAS(info + blockIdx.x, 0, off + bad);
       atomicAdd(logdet + blockIdx.x, lg);
     }
     return;
   }
+  // test hook (gpc_set_option "leaf_fault"): one update wave never shows up, so every hand-off it owes times out
+  if (fault && w == 1) return;
   if (w == 1)
     update_wave<T, 0>(sh, Ab, lda, Wb, ldw, lane, np, bad);
   else if (w == 2)
     update_wave<T, 1>(sh, Ab, lda, Wb, ldw, lane, np, bad);
   else
     update_wave<T, 2>(sh, Ab, lda, Wb, ldw, lane, np, bad);
-  if (bad && lane == 0) atomicCAS(info + blockIdx.x, 0, off + 1);  // a hand-off timed out (never expected)
+  if (bad && lane == 0) atomicOr(info + blockIdx.x, LEAF_TIMEOUT);  // a hand-off timed out (never expected)
 }
 
 inline int g_leaf_version = 5;  // 5: pipelined leaf5 (default), 3: the barrier-per-phase leaf3
+inline int g_leaf_fault = 0;    // test hook: leaf5 runs with a missing update wave (its hand-offs time out)
 
 template <typename T>
 inline void launch_leaf(hipStream_t st, int batch, T* A, long long sA, int lda, T* W, long long sW, int ldw, int off,
-                        double* logdet, int* info, int nvalid) {
-  if (g_leaf_version == 3)
-    hipLaunchKernelGGL((leaf3_kernel<T>), dim3(batch), dim3(256), 0, st, A, sA, lda, W, sW, ldw, off, logdet, info,
+                        double* logdet, int* info, int nvalid, bool stable = false) {
+  if (stable)
+    hipLaunchKernelGGL((leaf3_kernel<T, true>), dim3(batch), dim3(256), 0, st, A, sA, lda, W, sW, ldw, off, logdet, info,
+                       nvalid);
+  else if (g_leaf_version == 3)
+    hipLaunchKernelGGL((leaf3_kernel<T, false>), dim3(batch), dim3(256), 0, st, A, sA, lda, W, sW, ldw, off, logdet, info,
                        nvalid);
   else
     hipLaunchKernelGGL((leaf5_kernel<T>), dim3(batch), dim3(256), 0, st, A, sA, lda, W, sW, ldw, off, logdet, info,
-                       nvalid);
+                       nvalid, g_leaf_fault);
 }
 
 }  // namespace gpc

@@ -45,8 +45,23 @@ struct Factor {
   hipStream_t side = nullptr;
   hipEvent_t* evs = nullptr;  // pool of events for the fork / join pairs
   int nev = 0, ev_used = 0;
-  int defer_min = 0, reserve = 0;
+  int defer_min = 0;
+  const unsigned short* reserve = nullptr;  // table of the CUs a deferred launch stays off (gemm.h: cu_reserve_bail)
+  // debug (gpc_set_option "check_queues"): the persistent launches issued, for a check after the pipeline that
+  // every tile queue was drained
+  struct QueueCheck {
+    int* slot;
+    int ntiles, batch;
+  };
+  std::vector<QueueCheck>* qlog = nullptr;
   bool dual_launch = g_dual_launch;  // syrk + inverse product of a node in one launch where both are small
+  // Stable mode (the jitter retries, gpcore.hip: retry_failed): the trsm-as-a-product T21 = A21 W11^T has an error of
+  // cond(L11) eps instead of eps, which on a numerically singular matrix makes the factorization fail where a
+  // triangular solve (LAPACK, the reference) succeeds -- the device needed 1-2 decades more jitter than the reference
+  // on 7 of 8 singular fixture samples and never less (tools/jitter_model.py reproduces it on the CPU).  One step of
+  // refinement against the factor itself, T21 += (A21 - T21 L11^T) W11^T, at every node and in the leaf's panel
+  // solve (leaf.h: STABLE) restores the accuracy of a solve; L21 is kept in A so that L11 is a complete operand.
+  bool stable = false;
   // rows >= tail_row0 of A are still being built on the side stream (covfun.h: build_persist_kernel); the first
   // launch that touches them waits for ev_tail
   hipEvent_t ev_tail = nullptr;
@@ -88,7 +103,7 @@ struct Factor {
 
   void gemm(T* C, long long sC, const T* Aop, long long sAop, const T* Bop, long long sBop, int M,
             int N, int K, bool akm, bool bkm, double alpha, int beta, int klo, int khi, int lower,
-            hipStream_t on = nullptr, int rsv = 0) {
+            hipStream_t on = nullptr, const unsigned short* rsv = nullptr) {
     GemmArgs g;
     g.A = Aop;
     g.B = Bop;
@@ -108,15 +123,16 @@ struct Factor {
     g.tiles_n = N / TILE;
     flops += gemm_flops(g, batch);
     ++launches;
-    int* slot = nullptr;  // NQ counters per persistent launch
+    int* slot = nullptr;  // CTR_STRIDE counters per persistent launch
     // only launches that will run in the persistent form take a slot: a factorization of npad = 8192 or
     // 16384 has 250-500 launches, and the big ones (which need the slots) come last in the order
     const long long tm = M / TILE, tn = N / TILE;
     const long long blocks128 = (lower ? tm * (tm + 1) / 2 : tm * tn) * batch;
     const bool persistent = rsv || (blocks128 >= g_small_launch_blocks && blocks128 > g_block_slots - g_persist_spare);
-    if (persistent && ctr && ctr_used + NQ <= ctr_cap) {
+    if (persistent && ctr && ctr_used + CTR_STRIDE <= ctr_cap) {
       slot = ctr + ctr_used;
-      ctr_used += NQ;
+      ctr_used += CTR_STRIDE;
+      if (qlog) qlog->push_back({slot, (int)(lower ? tm * (tm + 1) / 2 : tm * tn), batch});
     }
     hipError_t e = launch_gemm<T>(on ? on : st, g, akm, bkm, batch, 0, slot, rsv);
     if (e != hipSuccess && err == hipSuccess) err = e;
@@ -127,10 +143,11 @@ struct Factor {
   }
 
   void potrf_inv(int off, int n, bool need_inv, bool keep_L) {
+    keep_L = keep_L || stable;
     if (n == TILE) {
       need_rows(off + TILE);
       launch_leaf<T>(st, batch, blk(A, off, off), sA, npad, blk(W, off, off), sW, npad, off, logdet, info,
-                     std::max(0, std::min(TILE, nvalid - off)));
+                     std::max(0, std::min(TILE, nvalid - off)), stable);
       flops += (2.0 / 3.0) * TILE * (double)TILE * TILE * batch;
       ++launches;
       return;
@@ -143,6 +160,13 @@ struct Factor {
     // 2. T21 = A21 * W11^T
     gemm(blk(Tm, o2, o1), sT, blk(A, o2, o1), sA, blk(W, o1, o1), sW, n2, n1, n1, false, false, 1.0,
          0, KLO_ZERO, KHI_COL, 0);
+    if (stable) {
+      // 2b. R = A21 - T21 * L11^T (in place: A21 is only ever the C operand), T21 += R * W11^T
+      gemm(blk(A, o2, o1), sA, blk(Tm, o2, o1), sT, blk(A, o1, o1), sA, n2, n1, n1, false, false, -1.0, 1, KLO_ZERO,
+           KHI_COL, 0);
+      gemm(blk(Tm, o2, o1), sT, blk(A, o2, o1), sA, blk(W, o1, o1), sW, n2, n1, n1, false, false, 1.0, 1, KLO_ZERO,
+           KHI_COL, 0);
+    }
     const bool defer = need_inv && side && defer_min > 0 && n >= defer_min && ev_used + 2 <= nev;
     // 3. A22 -= T21 * T21^T  -- and, where both are small launches, 5a. U = T21 * W11 -> A21 in the same launch:
     // it waits for T21 only (A21 has been consumed by step 2), and a launch less per node is ~5 us less

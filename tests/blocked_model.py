@@ -68,11 +68,53 @@ def leaf(Ablk, Wblk):
     return 0
 
 
-def potrf_inv(A, W, T, off, n, tile, need_inv, post_mode, log=None):
-    """Recursive plan on the n x n diagonal block starting at `off`."""
+def leaf_panels(Ablk, Wblk, pw=16, refine=False):
+    """The device leaf's own arithmetic (gpyreg_amd/csrc/leaf.h): right-looking with `pw`-wide panels, the panel
+    solve L_iP = A_iP W_PP^T as a PRODUCT with the explicit inverse of the pw x pw diagonal block; with `refine`
+    (the device's stable mode) followed by one step of refinement, L_iP += (A_iP - L_iP L_PP^T) W_PP^T."""
+    n = Ablk.shape[0]
+    S = np.tril(Ablk) + np.tril(Ablk, -1).T
+    L = np.zeros((n, n))
+    for p in range(0, n, pw):
+        P = slice(p, min(p + pw, n))
+        m = P.stop - P.start
+        Lpp = np.tril(S[P, P]).copy()
+        for j in range(m):  # pivot by reciprocal square root, column scaled by multiplication (leaf.h: diag16)
+            d = Lpp[j, j]
+            if not (d > 0):
+                return p + j + 1
+            r = 1.0 / np.sqrt(d)
+            Lpp[j:, j] *= r
+            for k in range(j + 1, m):
+                Lpp[k:, k] -= Lpp[k:, j] * Lpp[k, j]
+        L[P, P] = Lpp
+        if P.stop < n:
+            R = slice(P.stop, n)
+            Wpp = np.linalg.solve(Lpp, np.eye(m))
+            Lr = S[R, P] @ Wpp.T
+            if refine:
+                Lr = Lr + (S[R, P] - Lr @ Lpp.T) @ Wpp.T
+            L[R, P] = Lr
+            S[R, R] -= Lr @ Lr.T
+    Ablk[np.tril_indices(n)] = L[np.tril_indices(n)]
+    if refine:
+        Ablk[np.triu_indices(n, 1)] = 0.0  # stable mode: L11 becomes a GEMM operand, its diagonal tiles must be clean
+    Wblk[:, :] = np.linalg.solve(L, np.eye(n))
+    Wblk[np.triu_indices(n, 1)] = 0.0
+    return 0
+
+
+def potrf_inv(A, W, T, off, n, tile, need_inv, post_mode, log=None, stable=False, leaf_fn=None):
+    """Recursive plan on the n x n diagonal block starting at `off`.
+
+    ``stable`` (the device's mode for jitter retries, plan.h): the trsm-as-a-product T21 = A21 W11^T is followed by
+    one step of refinement against the factor itself, T21 += (A21 - T21 L11^T) W11^T, which makes the panel as
+    accurate as a triangular solve when L11 is ill-conditioned (tools/jitter_model.py); L21 is kept in A at every
+    node so that L11 is a complete operand."""
+    post_mode = post_mode or stable
     if n == tile:
         s = slice(off, off + n)
-        info = leaf(A[s, s], W[s, s])
+        info = (leaf_fn or leaf)(A[s, s], W[s, s])
         if log is not None:
             log["launches"] = log.get("launches", 0) + 1
         return info + off if info else 0
@@ -81,16 +123,22 @@ def potrf_inv(A, W, T, off, n, tile, need_inv, post_mode, log=None):
     n2 = n - n1
     o1, o2 = off, off + n1
     r1, r2 = slice(o1, o1 + n1), slice(o2, o2 + n2)
-    info = potrf_inv(A, W, T, o1, n1, tile, True, post_mode, log)
+    info = potrf_inv(A, W, T, o1, n1, tile, True, post_mode, log, stable, leaf_fn)
     if info:
         return info
     # step 2: T21 = A21 * W11^T      (W11 lower: k <= col)
     tiled_gemm(T[r2, r1], A[r2, r1], W[r1, r1], n2, n1, n1, tile, a_kmajor=False,
                b_kmajor=False, alpha=1.0, beta=0.0, khi=KHI_COL, log=log)
+    if stable:
+        # step 2b: R = A21 - T21 * L11^T (in place in A21; L11 lower: k <= col), T21 += R * W11^T
+        tiled_gemm(A[r2, r1], T[r2, r1], A[r1, r1], n2, n1, n1, tile, a_kmajor=False,
+                   b_kmajor=False, alpha=-1.0, beta=1.0, khi=KHI_COL, log=log)
+        tiled_gemm(T[r2, r1], A[r2, r1], W[r1, r1], n2, n1, n1, tile, a_kmajor=False,
+                   b_kmajor=False, alpha=1.0, beta=1.0, khi=KHI_COL, log=log)
     # step 3: A22 -= T21 * T21^T     (lower tiles only)
     tiled_gemm(A[r2, r2], T[r2, r1], T[r2, r1], n2, n2, n1, tile, a_kmajor=False,
                b_kmajor=False, alpha=-1.0, beta=1.0, lower_only=True, log=log)
-    info = potrf_inv(A, W, T, o2, n2, tile, need_inv, post_mode, log)
+    info = potrf_inv(A, W, T, o2, n2, tile, need_inv, post_mode, log, stable, leaf_fn)
     if info:
         return info
     if need_inv:

@@ -17,6 +17,9 @@ Files written next to this script:
                    f2 = the reference's own examples/example_1.py model and data
   fullsize_cases.npz   nlZ and dnlZ of BASELINE cfg2 (sample 0) and cfg3 (samples 0, 1, 15)
                    at full size (N = 2048 / 4096), a few dozen doubles
+  fullsize45_cases.npz the same at cfg4 (N = 16384, RQ: nlZ only -- the reference's (N, N, 22) gradient
+                   tensor would need 47 GB) and cfg5 (N = 8192, S = 64: samples 0 and 63 with gradient,
+                   7 and 8 nlZ only); run with the target `fullsize45`
   rank1_cases.npz  GP.update with ONE new point (the reference's rank-one path,
                    gaussian_process.py:750-844), high- and low-noise parametrisation
 """
@@ -479,6 +482,37 @@ def fullsize_cases():
     np.savez_compressed(os.path.join(HERE, "fullsize_cases.npz"), **out)
 
 
+def fullsize45_cases():
+    """Reference values at the two largest BASELINE configurations (inputs regenerated from the seed)."""
+    import time
+
+    out = {}
+    for cfg_idx, N, D, kname, S, rows_grad, rows_nll in [(5, 8192, 8, "se", 64, [0, 63], [7, 8]),
+                                                         (4, 16384, 20, "rq", 1, [], [0])]:
+        X, y, hyp = _bench_problem(cfg_idx, N, D, kname, S)
+        gp = gpr.GP(D=D, covariance=KERNELS[kname](), mean=MEANS["const"](), noise=make_noise((1, 0, 0)))
+        gp.X, gp.y = X, y
+        nl, dn = [], []
+        for s in rows_grad:
+            t0 = time.time()
+            a, b = gp._GP__compute_nlZ(hyp[s], True, False)
+            nl.append(a)
+            dn.append(b)
+            print(f"cfg{cfg_idx} s={s}: nlZ={a!r} ({time.time() - t0:.1f} s)", flush=True)
+        for s in rows_nll:
+            t0 = time.time()
+            a = gp._GP__compute_nlZ(hyp[s], False, False)
+            nl.append(a)
+            print(f"cfg{cfg_idx} s={s}: nlZ={a!r} (no gradient, {time.time() - t0:.1f} s)", flush=True)
+        out[f"cfg{cfg_idx}_rows"] = np.array(rows_grad + rows_nll)
+        out[f"cfg{cfg_idx}_rows_with_grad"] = np.array(rows_grad, dtype=int)
+        out[f"cfg{cfg_idx}_hyp"] = hyp[rows_grad + rows_nll]
+        out[f"cfg{cfg_idx}_nlZ"] = np.array(nl)
+        out[f"cfg{cfg_idx}_dnlZ"] = np.stack(dn) if dn else np.zeros((0, hyp.shape[1]))
+        out[f"cfg{cfg_idx}_Xsum"] = np.array([X.sum(), y.sum()])
+    np.savez_compressed(os.path.join(HERE, "fullsize45_cases.npz"), **out)
+
+
 def rank1_cases():
     """GP.update(X_new=1 point, y_new) through the reference's rank-one path (:750-844):
     three consecutive appends; posterior fields after the last one, predictions after each."""
@@ -544,6 +578,8 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["cov", "core", "prior", "fit", "full", "fullsize", "rank1"]
     if "fullsize" in which:
         fullsize_cases()
+    if "fullsize45" in which:  # not in the default list: ~10 minutes and ~15 GB of host memory
+        fullsize45_cases()
     if "rank1" in which:
         rank1_cases()
     if "cov" in which:

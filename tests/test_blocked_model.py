@@ -75,3 +75,68 @@ def test_plan_reports_first_bad_pivot():
     W = np.zeros((n, n))
     T = np.zeros((n, n))
     assert bm.potrf_inv(A, W, T, 0, n, tile, True, False) == 10
+
+
+@pytest.mark.parametrize("n,tile", [(12, 4), (37, 4), (64, 8)])
+def test_stable_mode_plan_is_the_same_factorization(n, tile):
+    """plan.h's stable mode (jitter retries): the refinement launches T21 += (A21 - T21 L11^T) W11^T read L11 out
+    of A -- complete there because L21 is kept at every node, with clean diagonal tiles -- and change nothing but
+    rounding on a well-conditioned matrix."""
+    rng = np.random.default_rng(n + tile)
+    A0 = _spd(n, rng)
+    out = []
+    for stable in (False, True):
+        A = bm.pad_identity(A0, tile)
+        npad = A.shape[0]
+        A[np.triu_indices(npad, 1)] = np.nan
+        W = np.zeros((npad, npad))
+        T = np.full((npad, npad), np.nan)
+        assert bm.potrf_inv(A, W, T, 0, npad, tile, True, False, stable=stable,
+                            leaf_fn=lambda a, w: bm.leaf_panels(a, w, 2, refine=stable)) == 0
+        out.append((np.tril(A) if stable else None, W))
+    L = np.linalg.cholesky(bm.pad_identity(A0, tile))
+    assert np.allclose(out[1][0], L, rtol=1e-10, atol=1e-12)
+    assert np.allclose(out[0][1], out[1][1], rtol=1e-9, atol=1e-12)
+
+
+def test_stable_mode_needs_no_more_jitter_than_lapack_on_a_singular_matrix():
+    """The reason stable mode exists (tools/jitter_model.py): near-duplicate inputs, tiny noise.  The fast plan
+    (explicit-inverse panel solves) fails at jitter levels where LAPACK succeeds; the stable plan does not."""
+    import scipy.linalg as sla
+
+    rng = np.random.default_rng(3)
+    worse = {False: 0, True: 0}
+    for trial in range(12):
+        N = 40 + 3 * trial
+        X = rng.uniform(-3, 3, (N, 2))
+        X[N // 2:] = X[:N - N // 2] + 1e-7 * rng.standard_normal((N - N // 2, 2))
+        K = np.exp(-0.5 * ((X[:, None, :] - X[None, :, :]) ** 2).sum(-1))
+        s = 10.0 ** rng.uniform(-20, -16)
+
+        def first_level(fact):
+            for k in range(14):
+                with np.errstate(all="ignore"):
+                    if fact(K + 10.0 ** k * s * np.eye(N)):
+                        return k
+            return 99
+
+        def lapack(A):
+            try:
+                sla.cholesky(A, lower=True, check_finite=False)
+                return True
+            except sla.LinAlgError:
+                return False
+
+        def plan(stable):
+            def f(A):
+                P = bm.pad_identity(A, 32)
+                n = P.shape[0]
+                return bm.potrf_inv(P, np.zeros((n, n)), np.zeros((n, n)), 0, n, 32, True, False, stable=stable,
+                                    leaf_fn=lambda a, w: bm.leaf_panels(a, w, 16, refine=stable)) == 0
+            return f
+
+        base = first_level(lapack)
+        for stable in (False, True):
+            worse[stable] += first_level(plan(stable)) > base
+    assert worse[False] >= 6, worse   # the fast plan is one-sidedly worse ...
+    assert worse[True] <= 2, worse    # ... the stable one is not

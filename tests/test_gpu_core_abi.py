@@ -103,7 +103,7 @@ def test_nll_and_grad_match_golden(ctx, core_golden):
     from gpyreg_amd import _lib
 
     g = core_golden
-    report, worst, n_diff_mult = [], 0.0, 0
+    report, worst, n_diff_mult, above, below = [], 0.0, 0, [], []
     for name in g["names"]:
         tag, model, N, D, flavour = parse_core_name(name)
         X, y, hyp = g[tag + "_X"], g[tag + "_y"], g[tag + "_hyp"]
@@ -125,6 +125,7 @@ def test_nll_and_grad_match_golden(ctx, core_golden):
         for s in range(hyp.shape[0]):
             same = mult[s] == gm[s]
             n_diff_mult += not same
+            (above if mult[s] > gm[s] else below if mult[s] < gm[s] else []).append("%s s=%d: %g vs %g" % (tag, s, mult[s], gm[s]))
             checked = []
             assert abs(nlz0[s] - nlz[s]) <= 1e-12 * max(1.0, abs(nlz[s])), name  # NLL-only path == NLL of NLL+grad
             if plain:
@@ -137,8 +138,9 @@ def test_nll_and_grad_match_golden(ctx, core_golden):
                 # ratio between the first successful levels: rounding dependent, but bounded
                 assert 0.01 <= mult[s] / gm[s] <= 100, (name, mult, gm)
 
-                def single(log10_start, grad=True):
+                def single(log10_start, grad=True, stable=0):
                     ctx.set_option("start_mult_log10", log10_start)
+                    ctx.set_option("stable", stable)
                     try:
                         return ctx.nll_batch(
                             KID[model["kernel"]], model["degree"], _lib.F64, hyp[s:s + 1, :pin["cov_N"]],
@@ -147,12 +149,14 @@ def test_nll_and_grad_match_golden(ctx, core_golden):
                             None if pin["dsn2"] is None else pin["dsn2"][s:s + 1])
                     finally:
                         ctx.set_option("start_mult_log10", 0)
+                        ctx.set_option("stable", 0)
 
                 lvl = int(round(np.log10(mult[s])))
                 if lvl > 0:
-                    # (i) the escalation path (failed samples gathered, re-run as a sub-batch, results
-                    # scattered back) must reproduce, bit for bit, a run that STARTS at that level
-                    n1, d1, m1, _, i1 = single(lvl)
+                    # (i) the escalation path (failed samples gathered, re-run as a sub-batch IN STABLE MODE -- first at
+                    # the level that failed, then x 10 per level -- results scattered back) must reproduce, bit for
+                    # bit, a stable-mode run that STARTS at the level it ended on
+                    n1, d1, m1, _, i1 = single(lvl, stable=1)
                     assert i1[0] == 0 and m1[0] == mult[s], (name, s, m1)
                     assert n1[0] == nlz[s] and np.array_equal(d1[0], dnlz[s], equal_nan=True), (name, s, "retry path")
                     checked.append("retry==start@1e%d" % lvl)
@@ -198,6 +202,13 @@ def test_nll_and_grad_match_golden(ctx, core_golden):
     print("worst relative error over well-conditioned fixtures: %.3e" % worst)
     print("samples whose first successful jitter level differs from LAPACK's: %d of %d" %
           (n_diff_mult, 2 * len(g["names"])))
+    print("  above LAPACK's level:", above)
+    print("  below LAPACK's level:", below)
+    # A failed factorization is retried at the SAME level in stable mode (refined panel solves: the accuracy of a
+    # triangular solve) before the jitter goes up, so the device no longer needs systematically more jitter than the
+    # reference (round 2: 1-2 decades more on 7 of the 8 singular samples, never less).  What is left is the coin
+    # flip of a numerically indefinite matrix (tools/jitter_model.py: g029 at 10x has a negative fp64 eigenvalue).
+    assert len(above) <= 3, above
 
 
 def test_arithmetic_after_a_jitter_retry(ctx, core_golden):

@@ -81,6 +81,13 @@ def _worker(rank, world, port, q):
             out["err"] = "LinAlgError"
         except sharding.ShardError as e:
             out["err"] = "ShardError"
+        # the ranks disagree about the batch (unsynchronised RNG seeds in a caller): ShardError on both, not a silent
+        # stitching of rows of two different batches
+        try:
+            gp.nll_batch(hyp + (0.01 if rank == 1 else 0.0), compute_grad=False)
+            out["mismatch"] = "no exception"
+        except sharding.ShardError as e:
+            out["mismatch"] = "different batches" in str(e)
         # and the group is still usable afterwards
         n2, _ = gp.nll_batch(hyp, compute_grad=False)
         out["after"] = bool(np.isfinite(n2).all())
@@ -112,4 +119,5 @@ def test_sharded_gp_equals_unsharded_bitwise_two_ranks_one_gpu():
         for S in (5, 16):
             assert all(r[S].values()), (rank, S, sorted(k for k, v in r[S].items() if not v))
         assert r["err"] in ("LinAlgError", "ShardError"), r["err"]
+        assert r["mismatch"] is True, r["mismatch"]
         assert r["after"]

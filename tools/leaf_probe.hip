@@ -59,9 +59,9 @@ int main() {
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0, 0));
         if (ver == 3)
-          hipLaunchKernelGGL((leaf3_kernel<double>), dim3(blocks), dim3(256), 0, 0, dA, (long long)n * n, n, dW, (long long)n * n, n, 0, dlog, dinfo, n);
+          hipLaunchKernelGGL((leaf3_kernel<double, false>), dim3(blocks), dim3(256), 0, 0, dA, (long long)n * n, n, dW, (long long)n * n, n, 0, dlog, dinfo, n);
         else
-          hipLaunchKernelGGL((leaf5_kernel<double>), dim3(blocks), dim3(256), 0, 0, dA, (long long)n * n, n, dW, (long long)n * n, n, 0, dlog, dinfo, n);
+          hipLaunchKernelGGL((leaf5_kernel<double>), dim3(blocks), dim3(256), 0, 0, dA, (long long)n * n, n, dW, (long long)n * n, n, 0, dlog, dinfo, n, 0);
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float ms;
