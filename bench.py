@@ -270,12 +270,25 @@ def main():
         from gpyreg_amd import _lib as L_
 
         tf, cyc, ghz = ctx.mfma_peak(L_.F64 if dtype == "f64" else L_.F32)
-        traffic = {}
+        # Committed PMC traffic (PMC cannot be collected inside a timed run): the measurement taken on THIS code state
+        # (tools/source_hash.py over the library's sources) if there is one, else the newest one, flagged as such
+        traffic, traffic_state = {}, None
         import glob
-        tfiles = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_traffic.json")))
-        if tfiles:  # the most recent committed PMC measurement
-            with open(tfiles[-1]) as fh:
-                traffic = json.load(fh)
+        from tools.source_hash import source_hash
+
+        cur = source_hash()
+        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+        cands = []
+        for tf in tfiles:
+            with open(tf) as fh:
+                cands.append(json.load(fh))
+        match = [t for t in cands if t.get("source_sha256") == cur]
+        if match:
+            traffic, traffic_state = match[-1], "measured on this code state (source sha256 %s)" % cur[:12]
+        elif cands:
+            traffic = cands[-1]
+            traffic_state = "STALE: measured on source sha256 %s, this run is %s" % (
+                str(traffic.get("source_sha256", "unrecorded (round <= 2)"))[:12], cur[:12])
         out = {
             "metric": "GP-fits/sec (NLL+grad, N=4096 D=10)" if (args.config == 3 and grad)
             else f"GP {'fits' if grad else 'NLL evals'}/sec (N={N} D={cfg['D']})",
@@ -308,6 +321,7 @@ def main():
                 # + WRITE_SIZE; profiles/r*_pmc_summary.txt); PMC cannot be collected inside a timed run
                 "traffic": traffic.get("step_traffic_bytes") if (args.config == 3 and grad and dtype == "f64") else None,
                 "traffic_source": traffic.get("source") if (args.config == 3 and grad and dtype == "f64") else None,
+                "traffic_code_state": traffic_state if (args.config == 3 and grad and dtype == "f64") else None,
                 "flops_per_launch": flops_per_launch,
                 "launch_ms": fac * 1e3,
                 "device_ms_per_step": float(np.mean(tot_ms)),

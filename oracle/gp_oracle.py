@@ -396,7 +396,7 @@ def core(model, hyp, X, y, s2, compute_nlZ, compute_nlZ_grad, force_mult=None):
                 continue
             break
         sl = 1
-        if not compute_nlZ:
+        if not compute_nlZ and L is not None:
             pL = sla.solve_triangular(
                 -L,
                 sla.solve_triangular(L, np.eye(N), trans=1.0, check_finite=False),

@@ -182,10 +182,14 @@ def test_nll_and_grad_match_golden(ctx, core_golden):
                     # device's; printed).  nlZ is still within the bound; the VALUE check proper is
                     # made four decades up the same escalation ladder, where digits exist.
                     assert np.isfinite(nlz[s]) and np.isfinite(dnlz[s]).all() and e_n <= min(bar, 1.0), (name, s, e_n)
-                    up = lvl + 4
+                    up = lvl + 4  # (five where four decades leave 8 cond eps just above 1e-2)
+                    while True:
+                        y_n, y_d, cond2, _, gsc2 = orc.core_extended(model, hyp[s], X, y, s2, sn2_mult=10.0 ** up, with_scale=True)
+                        if 8 * cond2 * EPS < 1e-2 or up >= lvl + 6:
+                            break
+                        up += 1
                     n2, d2, m2, _, i2 = single(up)
                     assert i2[0] == 0 and m2[0] == 10.0 ** up, (name, s, m2)
-                    y_n, y_d, cond2, _, gsc2 = orc.core_extended(model, hyp[s], X, y, s2, sn2_mult=10.0 ** up, with_scale=True)
                     gsc2 = gsc2 * min(1.0, cond2 * EPS)
                     bar2 = max(1e-8, 8 * cond2 * EPS)
                     u_n, u_d = _errs(n2[0], d2[0], y_n, y_d, gsc2)

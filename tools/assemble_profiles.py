@@ -4,8 +4,36 @@ import collections, csv, glob, json, shutil, sys
 
 run, tag = sys.argv[1], sys.argv[2]
 O, P = f"gpurun_out/{run}", "profiles"
-shutil.copy(glob.glob(f"{O}/prof/*/*_kernel_stats.csv")[0], f"{P}/{tag}_kernel_stats_bench_cfg3.csv")
-shutil.copy(glob.glob(f"{O}/prof_g1/*/*_kernel_stats.csv")[0], f"{P}/{tag}_kernel_stats_bench_cfg3_groups1.csv")
+
+
+def one(pattern):
+    """exactly one file may match: a second one means the directory holds more than one run"""
+    f = glob.glob(pattern)
+    if len(f) != 1:
+        sys.exit(f"assemble_profiles: {len(f)} files match {pattern} (expected exactly 1): {f}\n"
+                 "refusing to assemble evidence from a directory that holds more than one run")
+    return f[0]
+
+
+def names_of(path, col):
+    return {r[col].replace("void gpc::", "").split("(")[0] for r in csv.DictReader(open(path))
+            if "gpc::" in r[col] or r[col].startswith("gpc::")}
+
+
+source = open(f"{O}/source.sha256").read().strip()
+stats, stats_g1 = one(f"{O}/prof/*/*_kernel_stats.csv"), one(f"{O}/prof_g1/*/*_kernel_stats.csv")
+pmc_files = {t: one(f"{O}/{t}/*/*counter_collection.csv") for t in ("pmc1", "pmc2", "pmc3")}
+# every pass ran the same program on the same code: the kernel-name sets must agree (the per-run extras of the
+# single-group stats run aside: it is the same bench with GPC_GROUPS=1)
+sets = {"stats": names_of(stats, "Name"), "stats_g1": names_of(stats_g1, "Name"),
+        **{t: names_of(f, "Kernel_Name") for t, f in pmc_files.items()}}
+ref_set = sets["stats_g1"]
+for k, v in sets.items():
+    if v != ref_set:
+        sys.exit(f"assemble_profiles: kernel-name sets differ between passes ({k} vs stats_g1): only in {k}: "
+                 f"{sorted(v - ref_set)}; only in stats_g1: {sorted(ref_set - v)} -- the passes are not of one code state")
+shutil.copy(stats, f"{P}/{tag}_kernel_stats_bench_cfg3.csv")
+shutil.copy(stats_g1, f"{P}/{tag}_kernel_stats_bench_cfg3_groups1.csv")
 shutil.copy(f"{O}/bench.json", f"{P}/{tag}_bench_cfg3.json")
 for line in open(f"{O}/prof_g1.log"):
     if line.startswith('{"metric"'):
@@ -18,10 +46,11 @@ for r in csv.DictReader(open(f"{P}/{tag}_kernel_stats_bench_cfg3_groups1.csv")):
 
 
 def load(t):
-    return list(csv.DictReader(open(glob.glob(f"{O}/{t}/*/*counter_collection.csv")[0])))
+    return list(csv.DictReader(open(pmc_files[t])))
 
 
 out = open(f"{P}/{tag}_pmc_summary.txt", "w")
+out.write(f"code state (tools/source_hash.py): {source}\n")
 out.write("rocprofv3 --pmc passes on `bench.py --steps 1 --warmup 1` (cfg3, default 2 sample groups + 3 single-group steps for the dominant kernel);\n"
           "counters summed per kernel name over the run; the last block lists the W^T W launch (gemm_persist_kernel<double,true,true,128,4>) per dispatch\n")
 per = {}
@@ -61,5 +90,6 @@ json.dump({"dominant_kernel_traffic_bytes": fetch + write, "dominant_kernel_fetc
            "dominant_kernel_write_bytes": write,
            "step_traffic_bytes": (tot_f * 2 + tot_w) * 1024 / nsteps,
            "step_note": "all kernels of one cfg3 NLL+grad step of 16 samples (run total of the PMC passes / 5 steps): 2 x FETCH_SIZE + WRITE_SIZE",
+           "source_sha256": source,
            "source": f"profiles/{tag}_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md)"},
           open(f"{P}/{tag}_traffic.json", "w"), indent=1)

@@ -4,8 +4,12 @@
 set -o pipefail
 TAG=${1:-run}; STEPS=${2:-5}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/$TAG; mkdir -p $O
+O=$R/gpurun_out/$TAG
+# a run directory holds ONE run: a reused tag must not leave the previous run's CSVs beside the new ones
+# (round 2's "r02f" set mixed two code states that way)
+rm -rf $O; mkdir -p $O
 cd $R
+python3 tools/source_hash.py > $O/source.sha256
 (timeout -k 10 700 python -m pytest tests -m gpu -q -s -p no:cacheprovider > $O/tests.log 2>&1; rc=$?; echo "pytest exit=$rc" >> $O/tests.log; tail -3 $O/tests.log; [ $rc -eq 0 -o $rc -eq 1 ]) \
 && (timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; rc=$?; echo "smoke exit=$rc" >> $O/smoke.log; tail -2 $O/smoke.log; [ $rc -eq 0 -o $rc -eq 1 ]) \
 && (timeout -k 10 400 python bench.py --steps $STEPS --warmup 2 > $O/bench.json 2> $O/bench.err; rc=$?; echo "bench exit=$rc"; cat $O/bench.json; tail -3 $O/bench.err; [ $rc -eq 0 -o $rc -eq 1 ]) \

@@ -1,7 +1,7 @@
 #!/bin/bash
 # bash tools/prof_cfg4.sh <tag>: cfg4 (N=16384 D=20 RQ fp32, S=1) evidence: bench line, rocprofv3 kernel stats,
 # and FETCH_SIZE / WRITE_SIZE / GRBM passes for the HBM-bound kernel-build regime (BASELINE.json configs[3])
-R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=${1:-cfg4}; O=$R/gpurun_out/$TAG; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=${1:-cfg4}; O=$R/gpurun_out/$TAG; rm -rf $O; mkdir -p $O; python3 $R/tools/source_hash.py > $O/source.sha256
 cd $R && timeout -k 10 300 python3 bench.py --config 4 --steps 5 --warmup 2 > $O/bench_cfg4.json 2> $O/bench_cfg4.err; echo "bench exit=$?"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --config 4 --steps 3 --warmup 1 --no-cpu-baseline > $O/prof.log 2>&1; echo "stats exit=$?"
