@@ -279,16 +279,17 @@ def main():
         cur = source_hash()
         tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
         cands = []
-        for tf in tfiles:
-            with open(tf) as fh:
+        for tfile in tfiles:
+            with open(tfile) as fh:
                 cands.append(json.load(fh))
         match = [t for t in cands if t.get("source_sha256") == cur]
         if match:
             traffic, traffic_state = match[-1], "measured on this code state (source sha256 %s)" % cur[:12]
         elif cands:
             traffic = cands[-1]
-            traffic_state = "STALE: measured on source sha256 %s, this run is %s" % (
-                str(traffic.get("source_sha256", "unrecorded (round <= 2)"))[:12], cur[:12])
+            old = traffic.get("source_sha256")
+            traffic_state = "STALE: measured on %s, this run is source sha256 %s" % (
+                ("source sha256 " + old[:12]) if old else "an unrecorded code state (round <= 2)", cur[:12])
         out = {
             "metric": "GP-fits/sec (NLL+grad, N=4096 D=10)" if (args.config == 3 and grad)
             else f"GP {'fits' if grad else 'NLL evals'}/sec (N={N} D={cfg['D']})",
