@@ -283,6 +283,7 @@ struct gpc_ctx {
   unsigned cu_seen[64] = {};
   bool cu_map_ok = false;
   DevBuf rsv_tbl;
+  int nll_block = 1024;  // NLL-only evaluations: largest diagonal block that gets its inverse (plan.h: potrf_nll; 0: round-2 scheme)
   int stable = 0;        // option: every factorization in stable mode (plan.h), not only the jitter retries
   int check_queues = 0;  // debug option: verify after every pipeline that the tile queues of its persistent launches were drained
   hipEvent_t ev_up = nullptr, ev_done[MAXG] = {};
@@ -320,7 +321,7 @@ struct gpc_ctx {
   static constexpr int NGRAPH = 16;
   GraphEntry graphs[NGRAPH];
   unsigned long long graph_clock = 0;
-  int graph_max_npad = 1024;     // GPC_GRAPH_MAX_NPAD (0 disables)
+  int graph_max_npad = 4096;     // GPC_GRAPH_MAX_NPAD (0 disables)
   bool capturing = false;
   DevBuf tile_ctr;               // counters of the persistent GEMM launches, CTR_PER_GROUP per sample group
   static constexpr int CTR_PER_GROUP = 1024;
@@ -760,7 +761,13 @@ struct Pipe {
     }
     // NLL only: the inverse of the whole matrix is not needed (only of left children)
     const bool full_inv = (mode != MODE_NLL);
-    F.potrf_inv(0, npad, full_inv, mode == MODE_POST);
+    const bool nll_blocked = mode == MODE_NLL && c->nll_block >= TILE && npad > c->nll_block;
+    if (nll_blocked) {
+      F.nll_block = c->nll_block;
+      F.potrf_nll(0, npad);
+    } else {
+      F.potrf_inv(0, npad, full_inv, mode == MODE_POST);
+    }
     if (mode == MODE_GRAD) {
       if (!c->capturing) HIPCHK(c, hipEventRecord(c->ev_l0[gidx], st));
       F.lauum(Tc, sM);
@@ -775,7 +782,10 @@ struct Pipe {
     c->last_flops += F.flops;
 
     // z = L^-1 r ; quad = z.z ; alpha = W^T z / sl
-    F.forward_solve(0, npad, full_inv, rvec, zvec);
+    if (nll_blocked)
+      F.forward_solve_nll(0, npad, rvec, zvec);
+    else
+      F.forward_solve(0, npad, full_inv, rvec, zvec);
     if (mode == MODE_NLL) {
       hipLaunchKernelGGL(dot_kernel, dim3(1, n), dim3(256), 0, st, (const double*)zvec, (const double*)zvec,
                          npad, npad, d_quad);
@@ -1032,7 +1042,10 @@ struct Pipe {
         defer_node = (npad / 2 / TILE) * TILE;
       if (defer_node > 0) groups = 1;
     }
-    if (groups == 1 && c->graph_max_npad > 0 && npad <= c->graph_max_npad && !kmode()) {
+    // Launch graphs: every one-group pipeline whose schedule lives on ONE stream (the deferred products and the split
+    // build fork to side streams with CU-reserving launches and stay eager).  Round 3: up to npad = 4096 (round 2
+    // stopped at 1024) -- N = 2000: 1.171 -> 1.137 ms, N = 4096: 3.03 -> 2.97 ms per single NLL+grad evaluation.
+    if (groups == 1 && defer_node == 0 && c->graph_max_npad > 0 && npad <= c->graph_max_npad && !kmode()) {
       int rc = graph_section(cnt);
       if (rc) return rc;
     } else if (groups == 1) {
@@ -2022,6 +2035,7 @@ int gpc_create(int device, gpc_ctx** out) {
   }
   if (const char* e = getenv("GPC_LEAF")) gpc::g_leaf_version = atoi(e) == 3 ? 3 : 5;
   if (const char* e = getenv("GPC_GRAPH_MAX_NPAD")) c->graph_max_npad = atoi(e);
+  if (const char* e = getenv("GPC_NLL_BLOCK")) c->nll_block = atoi(e) <= 0 ? 0 : std::max(TILE, (atoi(e) / TILE) * TILE);
   if (const char* e = getenv("GPC_GROUPS")) c->groups = std::max(1, std::min((int)gpc_ctx::MAXG, atoi(e)));
   if (const char* e = getenv("GPC_SMALL_BLOCKS")) gpc::g_small_launch_blocks = atoi(e);
   if (const char* e = getenv("GPC_DUAL")) gpc::g_dual_launch = atoi(e) != 0;
@@ -2450,6 +2464,8 @@ int gpc_set_option(gpc_ctx* c, const char* name, int value) {
     if (build_reserve_table(c)) return -1;
   } else if (n == "leaf_fault")  // test hook: the pipelined leaf runs with a missing wave, its hand-offs time out
     gpc::g_leaf_fault = value != 0;
+  else if (n == "nll_block")  // NLL-only: largest diagonal block with an inverse (multiple of 128; 0: left children inverted)
+    c->nll_block = value <= 0 ? 0 : std::max(TILE, (value / TILE) * TILE);
   else if (n == "stable")  // every factorization in stable mode (refined panel solves, plan.h), not only the jitter retries
     c->stable = value != 0;
   else if (n == "check_queues")  // debug: verify the tile queues of persistent launches after every pipeline

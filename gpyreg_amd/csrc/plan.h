@@ -225,6 +225,72 @@ struct Factor {
     }
   }
 
+  // ---- NLL only: A = L L^T at N^3/3 ---------------------------------------------------------------------------
+  // An evaluation without gradient (the design stage of fit, f_min_fill.py:174-176, and the slice sampler,
+  // slice_sample.py:442) needs log det and L^-1 r, not the inverse.  potrf_inv(.., need_inv = false) still inverts
+  // every LEFT child completely (its T21 = A21 W11^T wants W11): 0.381 N^3 flop.  Here only diagonal blocks of at
+  // most `nll_block` rows get their inverse (2 N nll_block^2 / 3 flop in all); above that size the panel
+  // T21 = A21 L11^-T is a BLOCKED triangular solve against the factor itself,
+  //     X_a = A21_a L_a^-T ;  A21_c -= X_a L_ca^T ;  X_c = A21_c L_c^-T        (L11 = [[L_a, 0], [L_ca, L_c]]),
+  // recursively, the base case a product with the inverse of a block of nll_block rows.  Same flops as the product
+  // with the full inverse, but no U / W21 products above nll_block rows.  L_ca is read where the inner node left it,
+  // in the scratch (its own T21).
+  int nll_block = 0;  // 0: off (potrf_inv with need_inv = false)
+
+  void trsm_nll(int r0, int m, int c0, int n) {
+    if (n <= nll_block) {
+      gemm(blk(Tm, r0, c0), sT, blk(A, r0, c0), sA, blk(W, c0, c0), sW, m, n, n, false, false, 1.0, 0, KLO_ZERO,
+           KHI_COL, 0);
+      if (stable) {  // refinement against the factor of the block, as in potrf_inv (L of the block is complete in A)
+        gemm(blk(A, r0, c0), sA, blk(Tm, r0, c0), sT, blk(A, c0, c0), sA, m, n, n, false, false, -1.0, 1, KLO_ZERO,
+             KHI_COL, 0);
+        gemm(blk(Tm, r0, c0), sT, blk(A, r0, c0), sA, blk(W, c0, c0), sW, m, n, n, false, false, 1.0, 1, KLO_ZERO,
+             KHI_COL, 0);
+      }
+      return;
+    }
+    const int q = n / TILE;
+    const int n1 = (q / 2) * TILE, n2 = n - n1;
+    trsm_nll(r0, m, c0, n1);
+    gemm(blk(A, r0, c0 + n1), sA, blk(Tm, r0, c0), sT, blk(Tm, c0 + n1, c0), sT, m, n2, n1, false, false, -1.0, 1,
+         KLO_ZERO, KHI_FULL, 0);
+    trsm_nll(r0, m, c0 + n1, n2);
+  }
+
+  void potrf_nll(int off, int n) {
+    if (n <= nll_block || n == TILE) {
+      potrf_inv(off, n, true, false);
+      return;
+    }
+    const int q = n / TILE;
+    const int n1 = (q / 2) * TILE, n2 = n - n1;
+    const int o1 = off, o2 = off + n1;
+    potrf_nll(o1, n1);
+    need_rows(o2 + n2);
+    trsm_nll(o2, n2, o1, n1);
+    gemm(blk(A, o2, o2), sA, blk(Tm, o2, o1), sT, blk(Tm, o2, o1), sT, n2, n2, n1, false, false, -1.0, 1, KLO_ZERO,
+         KHI_FULL, 1);
+    potrf_nll(o2, n2);
+  }
+
+  // z = L^-1 r after potrf_nll: blocks of at most nll_block rows multiply by their inverse, above that the solve
+  // splits like the factorization and eliminates with L21, in the scratch
+  void forward_solve_nll(int off, int n, double* r, double* z) {
+    if (n <= nll_block || n == TILE) {
+      hipLaunchKernelGGL((trmv_kernel<T>), dim3(n / 4, batch), dim3(256), 0, st, (const T*)W, sW, npad,
+                         (const double*)r, npad, z, off);
+      ++launches;
+      return;
+    }
+    const int q = n / TILE;
+    const int n1 = (q / 2) * TILE, n2 = n - n1;
+    forward_solve_nll(off, n1, r, z);
+    hipLaunchKernelGGL((gemv_sub_kernel<T>), dim3(n2 / 4, batch), dim3(256), 0, st, (const T*)Tm, sT, npad,
+                       (const double*)z, r, npad, off + n1, off, n1);
+    ++launches;
+    forward_solve_nll(off + n1, n2, r, z);
+  }
+
   // z = L^-1 r after potrf_inv(.., need_inv): blocks that own their full inverse multiply
   // by W, the others split like the factorization and eliminate with L21 (kept in A for
   // exactly those blocks).  r is consumed (updated in place); r, z: [batch][npad] doubles.

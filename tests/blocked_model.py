@@ -184,3 +184,54 @@ def forward_solve(T, W, r, off, n, tile, need_inv):
     forward_solve(T, W, r, off, n1, tile, True)
     r[r2] -= T[r2, r1] @ r[r1]
     forward_solve(T, W, r, off + n1, n2, tile, need_inv)
+
+
+def trsm_nll(A, W, T, r0, m, c0, n, tile, blk, log=None):
+    """plan.h: trsm_nll.  T[r0:, c0:] = A[r0:, c0:] L[c0:, c0:]^-T by blocks: blocks of at most `blk` rows own an
+    inverse, above that the solve splits like the factorization (A21 is updated in place)."""
+    rows = slice(r0, r0 + m)
+    if n <= blk:
+        c = slice(c0, c0 + n)
+        tiled_gemm(T[rows, c], A[rows, c], W[c, c], m, n, n, tile, a_kmajor=False, b_kmajor=False, alpha=1.0,
+                   beta=0.0, khi=KHI_COL, log=log)
+        return
+    q = n // tile
+    n1 = (q // 2) * tile
+    n2 = n - n1
+    ca, cc = slice(c0, c0 + n1), slice(c0 + n1, c0 + n)
+    trsm_nll(A, W, T, r0, m, c0, n1, tile, blk, log)
+    tiled_gemm(A[rows, cc], T[rows, ca], T[cc, ca], m, n2, n1, tile, a_kmajor=False, b_kmajor=False, alpha=-1.0,
+               beta=1.0, log=log)
+    trsm_nll(A, W, T, r0, m, c0 + n1, n2, tile, blk, log)
+
+
+def potrf_nll(A, W, T, off, n, tile, blk, log=None):
+    """plan.h: potrf_nll -- the factorization of an NLL-only evaluation at N^3/3."""
+    if n <= blk or n == tile:
+        return potrf_inv(A, W, T, off, n, tile, True, False, log)
+    q = n // tile
+    n1 = (q // 2) * tile
+    n2 = n - n1
+    o1, o2 = off, off + n1
+    r1, r2 = slice(o1, o1 + n1), slice(o2, o2 + n2)
+    info = potrf_nll(A, W, T, o1, n1, tile, blk, log)
+    if info:
+        return info
+    trsm_nll(A, W, T, o2, n2, o1, n1, tile, blk, log)
+    tiled_gemm(A[r2, r2], T[r2, r1], T[r2, r1], n2, n2, n1, tile, a_kmajor=False, b_kmajor=False, alpha=-1.0,
+               beta=1.0, lower_only=True, log=log)
+    return potrf_nll(A, W, T, o2, n2, tile, blk, log)
+
+
+def forward_solve_nll(T, W, r, off, n, tile, blk):
+    if n <= blk or n == tile:
+        s = slice(off, off + n)
+        r[s] = np.tril(W[s, s]) @ r[s]
+        return
+    q = n // tile
+    n1 = (q // 2) * tile
+    n2 = n - n1
+    r1, r2 = slice(off, off + n1), slice(off + n1, off + n)
+    forward_solve_nll(T, W, r, off, n1, tile, blk)
+    r[r2] -= T[r2, r1] @ r[r1]
+    forward_solve_nll(T, W, r, off + n1, n2, tile, blk)

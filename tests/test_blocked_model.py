@@ -140,3 +140,34 @@ def test_stable_mode_needs_no_more_jitter_than_lapack_on_a_singular_matrix():
             worse[stable] += first_level(plan(stable)) > base
     assert worse[False] >= 6, worse   # the fast plan is one-sidedly worse ...
     assert worse[True] <= 2, worse    # ... the stable one is not
+
+
+@pytest.mark.parametrize("n,tile,blk", [(32, 4, 4), (32, 4, 8), (44, 4, 8), (72, 4, 16), (64, 8, 8), (37, 4, 12)])
+def test_plan_nll_only_blocked_triangular_solves(n, tile, blk):
+    """plan.h: potrf_nll / trsm_nll / forward_solve_nll -- only diagonal blocks of at most `blk` rows are inverted,
+    the panels above are blocked solves against the factor in the scratch; N^3/3 flops; the strictly upper part of A
+    and everything outside the written regions is never read (NaN poison)."""
+    rng = np.random.default_rng(n + tile + blk)
+    A0 = _spd(n, rng)
+    A = bm.pad_identity(A0, tile)
+    npad = A.shape[0]
+    Aref = A.copy()
+    A[np.triu_indices(npad, 1)] = np.nan
+    W = np.full((npad, npad), np.nan)
+    for o in range(0, npad, tile):  # leaves write whole diagonal tiles of W
+        W[o:o + tile, o:o + tile] = 0
+    T = np.full((npad, npad), np.nan)
+    log = {}
+    assert bm.potrf_nll(A, W, T, 0, npad, tile, blk, log) == 0
+    Lref = np.linalg.cholesky(Aref)
+    assert np.allclose(np.diag(A), np.diag(Lref), rtol=1e-12)
+    r = rng.standard_normal(npad)
+    z = r.copy()
+    bm.forward_solve_nll(T, W, z, 0, npad, tile, blk)
+    assert np.allclose(z, np.linalg.solve(Lref, r), rtol=1e-9, atol=1e-12)
+    if npad // tile >= 8 and blk <= 2 * tile:
+        old = {}
+        A2 = bm.pad_identity(A0, tile)
+        bm.potrf_inv(A2, np.zeros((npad, npad)), np.zeros((npad, npad)), 0, npad, tile, False, False, old)
+        assert log["flops"] < 0.97 * old["flops"]            # fewer flops than inverting every left child ...
+        assert log["flops"] < 1.45 * npad**3 / 3               # ... and close to N^3/3 (+ the small inverses)

@@ -236,3 +236,37 @@ def test_stable_mode_is_the_same_factorization_up_to_rounding(ctx):
     finally:
         ctx.set_option("stable", 0)
         bench.CONFIGS[3] = bench_cfg
+
+
+def test_nll_only_blocked_solves_every_block_size(ctx):
+    """NLL-only evaluations factor at N^3/3 (plan.h: potrf_nll): only diagonal blocks of at most `nll_block` rows are
+    inverted, the panels above are blocked triangular solves against the factor.  Every block size -- and the
+    round-2 scheme, nll_block = 0 -- must give the NLL of the NLL+gradient path to rounding, the reference's values at
+    the headline sizes to 1e-8 (fullsize_cases.npz; callers: f_min_fill.py:174-176, slice_sample.py:442), in stable
+    mode too, and odd tile counts must work (N = 2304 = 18 tiles, 1408 = 11 tiles)."""
+    import bench
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fullsize_cases.npz"), allow_pickle=False)
+    bench_cfg = dict(bench.CONFIGS[3])
+    try:
+        for N, S in ((1408, 3), (2304, 5), (4096, 16)):
+            bench.CONFIGS[3] = dict(bench_cfg, N=N)
+            X, y, hyp = bench.synthetic_problem(3, S)
+            gp = bench.make_gp(3, "f64")
+            gp.update(X_new=X, y_new=y, hyp=hyp[:1], compute_posterior=False)
+            ref, _ = gp.nll_batch(hyp, compute_grad=True)
+            for blk in (0, 128, 256, 512, 1024, 2048):
+                for stable in (0, 1) if blk in (0, 512) else (0,):
+                    ctx.set_option("nll_block", blk)
+                    ctx.set_option("stable", stable)
+                    n0, _ = gp.nll_batch(hyp, compute_grad=False)
+                    assert np.abs(n0 - ref).max() <= 1e-12 * np.abs(ref).max(), (N, blk, stable)
+                    one, _ = gp.nll_batch(hyp[S - 1:S], compute_grad=False)
+                    assert one[0] == n0[S - 1], (N, blk, "batch == single")
+                    if N == 4096:
+                        for k, srow in enumerate(g["cfg3_rows"]):
+                            assert abs(n0[srow] - g["cfg3_nlZ"][k]) < 1e-8 * abs(g["cfg3_nlZ"][k]), (blk, srow)
+    finally:
+        ctx.set_option("nll_block", 1024)
+        ctx.set_option("stable", 0)
+        bench.CONFIGS[3] = bench_cfg
