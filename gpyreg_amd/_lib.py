@@ -60,6 +60,8 @@ SIGNATURES = {
     "gpc_predict": (C.c_int, [_vp, _dp, C.c_int, _dp, _dp]),
     "gpc_post_append": (C.c_int, [_vp, _dp, _dp, C.c_double, _ip]),
     "gpc_post_recompute": (C.c_int, [_vp, C.c_int, _ip, _dp, _dp, _dp, C.c_int, _dp, _ip, _ip]),
+    "gpc_post_append_K": (C.c_int, [_vp, _dp, _dp, _dp, _dp, C.c_double, _ip]),
+    "gpc_post_recompute_K": (C.c_int, [_vp, C.c_int, _ip, _dp, _dp, _dp, C.c_int, _dp, _ip, _ip]),
     "gpc_predict_full": (C.c_int, [_vp, _dp, C.c_int, _dp, _dp]),
     "gpc_quad": (C.c_int, [_vp, _dp, _dp, C.c_int, C.c_int, _dp, _dp]),
     "gpc_last_timing": (C.c_int, [_vp, _dp, _dp]),
@@ -366,14 +368,37 @@ class PostHandle:
         self.N += 1
         return ok.astype(bool)
 
-    def recompute(self, idx, hyp_cov, m, sn2, sn2_is_vector):
-        """Full recompute of the listed samples in place (the reference's ``full_updates``)."""
+    def append_K(self, Ks, kss, m_star, sn2_star, y_new):
+        """``append`` for posteriors built from a caller's covariance object: Ks (S, n) = k_s(X_old, x_new),
+        kss (S,) = k_s(x_new, x_new)."""
+        Ks, kss = _f64(Ks), _f64(kss).ravel()
+        m_star, sn2_star = _f64(m_star).ravel(), _f64(sn2_star).ravel()
+        if Ks.shape != (self.S, self.N) or kss.shape != (self.S,):
+            raise ValueError("Ks must be (S, n) and kss (S,)")
+        ok = np.zeros(self.S, dtype=np.int32)
+        rc = self.ctx._lib.gpc_post_append_K(self._h, _ptr(Ks), _ptr(kss), _ptr(m_star), _ptr(sn2_star),
+                                             float(y_new), ok.ctypes.data_as(_ip))
+        self.ctx._check(rc, "gpc_post_append_K")
+        self.N += 1
+        return ok.astype(bool)
+
+    def recompute(self, idx, hyp_cov, m, sn2, sn2_is_vector, K=None):
+        """Full recompute of the listed samples in place (the reference's ``full_updates``).  ``K`` (cnt, N, N):
+        the caller's covariance matrices on the extended data (posteriors built from a covariance object)."""
         idx = np.ascontiguousarray(idx, dtype=np.int32)
-        hyp_cov, m, sn2 = _f64(hyp_cov), _f64(m), _f64(sn2)
+        m, sn2 = _f64(m), _f64(sn2)
         cnt = idx.size
         mult = np.empty(cnt)
         lchol = np.empty(cnt, dtype=np.int32)
         info = np.empty(cnt, dtype=np.int32)
+        if K is not None:
+            K = _f64(K)
+            rc = self.ctx._lib.gpc_post_recompute_K(
+                self._h, cnt, idx.ctypes.data_as(_ip), _ptr(K), _ptr(m), _ptr(sn2),
+                1 if sn2_is_vector else 0, _ptr(mult), lchol.ctypes.data_as(_ip), info.ctypes.data_as(_ip))
+            self.ctx._check(rc, "gpc_post_recompute_K")
+            return mult, lchol.astype(bool), info
+        hyp_cov = _f64(hyp_cov)
         rc = self.ctx._lib.gpc_post_recompute(
             self._h, cnt, idx.ctypes.data_as(_ip), _ptr(hyp_cov), _ptr(m), _ptr(sn2),
             1 if sn2_is_vector else 0, _ptr(mult), lchol.ctypes.data_as(_ip), info.ctypes.data_as(_ip))

@@ -283,7 +283,13 @@ struct gpc_ctx {
   unsigned cu_seen[64] = {};
   bool cu_map_ok = false;
   DevBuf rsv_tbl;
-  int nll_block = 1024;  // NLL-only evaluations: largest diagonal block that gets its inverse (plan.h: potrf_nll; 0: round-2 scheme)
+  // NLL-only evaluations: largest diagonal block that gets its inverse (plan.h: potrf_nll).  0: round-2 scheme (every
+  // left child inverted); -1: automatic -- 512 when the batch is throughput-bound, S (npad/4096)^3 >= 1.5, else 0.
+  // Measured (tools/nll_block_sweep.py, ms per batch at block 0 / 256 / 512 / 1024): cfg3 S=16 8.85 / 8.50 / 8.41 / 8.46;
+  // N=8192 S=8 29.8 / 28.1 / 27.5 / 27.5; N=2048 S=16 1.98 / 1.95 / 1.89 / 2.00; single samples and small batches are
+  // launch-bound and lose with the extra launches of the blocked solves (N=4096 S=1 2.28 / 2.42 / 2.30 / 2.28;
+  // N=2048 S=1 0.96 / 1.01 / 0.98 / 0.98; N=1000 S=8 0.52 / 0.53 / 0.54 / 0.54).
+  int nll_block = -1;
   int stable = 0;        // option: every factorization in stable mode (plan.h), not only the jitter retries
   int check_queues = 0;  // debug option: verify after every pipeline that the tile queues of its persistent launches were drained
   hipEvent_t ev_up = nullptr, ev_done[MAXG] = {};
@@ -761,9 +767,11 @@ struct Pipe {
     }
     // NLL only: the inverse of the whole matrix is not needed (only of left children)
     const bool full_inv = (mode != MODE_NLL);
-    const bool nll_blocked = mode == MODE_NLL && c->nll_block >= TILE && npad > c->nll_block;
+    const int nll_blk = c->nll_block >= 0 ? c->nll_block
+                                          : ((double)n * std::pow((double)npad / 4096.0, 3.0) >= 1.5 ? 512 : 0);
+    const bool nll_blocked = mode == MODE_NLL && nll_blk >= TILE && npad > nll_blk;
     if (nll_blocked) {
-      F.nll_block = c->nll_block;
+      F.nll_block = nll_blk;
       F.potrf_nll(0, npad);
     } else {
       F.potrf_inv(0, npad, full_inv, mode == MODE_POST);
@@ -1811,8 +1819,11 @@ int debug_factor_impl(gpc_ctx* c, int n, const double* A, double* L, double* W, 
 namespace {
 // rank-one append (scalar noise; checked by the caller): high-noise samples get a new last row
 // of the factor and of its inverse (:776-817), low-noise samples a rank-one update of -inv (:819-827)
+// Ks_h / kss_h: the cross covariances and prior variances at the new point from the caller's own covariance object
+// (K-mode posteriors); nullptr: built on the device from the posterior's kernel
 template <typename T>
-int append_impl(gpc_post* po, const double* m_star, const double* sn2_star, double y_new, int* ok) {
+int append_impl(gpc_post* po, const double* m_star, const double* sn2_star, double y_new, int* ok,
+                const double* Ks_h = nullptr, const double* kss_h = nullptr) {
   gpc_ctx* c = po->ctx;
   const int S = po->S, D = po->D, n = po->N;  // the new point is row n of the context's X
   hipStream_t st = c->st;
@@ -1852,9 +1863,9 @@ int append_impl(gpc_post* po, const double* m_star, const double* sn2_star, doub
   HIPCHK(c, c->tpart.ensure((size_t)S * (npad / TRC + 1) * vb));
   HIPCHK(c, c->scal.ensure((size_t)S * 10 * 8));
   HIPCHK(c, hipMemcpyAsync(c->spb.p, po->sp.data(), (size_t)S * SP_STRIDE * 8, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(c->mulb.p, po->mul.data(), (size_t)S * D * 8, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(c->divb.p, po->dv.data(), (size_t)S * D * 8, hipMemcpyHostToDevice, st));
-  {
+  if (!Ks_h) {
+    HIPCHK(c, hipMemcpyAsync(c->mulb.p, po->mul.data(), (size_t)S * D * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->divb.p, po->dv.data(), (size_t)S * D * 8, hipMemcpyHostToDevice, st));
     const long long tot = (long long)npad * D;
     hipLaunchKernelGGL(scale_x_kernel, dim3((unsigned)((tot + 255) / 256), S), dim3(256), 0, st,
                        c->dX.as<double>(), n + 1, npad, D, c->mulb.as<double>(), c->divb.as<double>(),
@@ -1865,8 +1876,13 @@ int append_impl(gpc_post* po, const double* m_star, const double* sn2_star, doub
   double* au = c->avec.as<double>();  // W^T l
   double* d_ll = c->scal.as<double>();
   double* d_ka = d_ll + S;
-  hipLaunchKernelGGL(cross_vec_kernel, dim3((npad + 255) / 256, S), dim3(256), 0, st, po->cd,
-                     c->xs.as<double>(), c->spb.as<double>(), n, npad, ks);
+  if (Ks_h) {  // rows of n values, zero beyond (the padding rows of W are identity rows)
+    HIPCHK(c, hipMemsetAsync(ks, 0, S * vb, st));
+    HIPCHK(c, hipMemcpy2DAsync(ks, vb, Ks_h, (size_t)n * 8, (size_t)n * 8, S, hipMemcpyHostToDevice, st));
+  } else {
+    hipLaunchKernelGGL(cross_vec_kernel, dim3((npad + 255) / 256, S), dim3(256), 0, st, po->cd,
+                       c->xs.as<double>(), c->spb.as<double>(), n, npad, ks);
+  }
   hipLaunchKernelGGL((trmv_kernel<T>), dim3(npad / 4, S), dim3(256), 0, st, (const T*)po->W.as<T>(), sM, npad,
                      (const double*)ks, npad, lv, 0);
   hipLaunchKernelGGL(dot_kernel, dim3(1, S), dim3(256), 0, st, (const double*)lv, (const double*)lv, n, npad, d_ll);
@@ -1904,7 +1920,7 @@ int append_impl(gpc_post* po, const double* m_star, const double* sn2_star, doub
   if (any_low) HIPCHK(c, hipMemcpyAsync(kau.data(), d_kau, S * 8, hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));
   for (int s = 0; s < S; ++s) {
-    const double sf2 = po->sp[(size_t)s * SP_STRIDE + SP_SF2];
+    const double sf2 = kss_h ? kss_h[s] : po->sp[(size_t)s * SP_STRIDE + SP_SF2];  // k(x_new, x_new)
     const double sl = po->sp[(size_t)s * SP_STRIDE + SP_SL];  // = sn2 * sn2_mult of the fitted noise (L_chol)
     const double sn2_eff = sn2_star[s] * po->mult[s];
     const double mu_star = m_star[s] + ka[s];  // predictive mean at the new point
@@ -2035,7 +2051,7 @@ int gpc_create(int device, gpc_ctx** out) {
   }
   if (const char* e = getenv("GPC_LEAF")) gpc::g_leaf_version = atoi(e) == 3 ? 3 : 5;
   if (const char* e = getenv("GPC_GRAPH_MAX_NPAD")) c->graph_max_npad = atoi(e);
-  if (const char* e = getenv("GPC_NLL_BLOCK")) c->nll_block = atoi(e) <= 0 ? 0 : std::max(TILE, (atoi(e) / TILE) * TILE);
+  if (const char* e = getenv("GPC_NLL_BLOCK")) c->nll_block = atoi(e) < 0 ? -1 : (atoi(e) == 0 ? 0 : std::max(TILE, (atoi(e) / TILE) * TILE));
   if (const char* e = getenv("GPC_GROUPS")) c->groups = std::max(1, std::min((int)gpc_ctx::MAXG, atoi(e)));
   if (const char* e = getenv("GPC_SMALL_BLOCKS")) gpc::g_small_launch_blocks = atoi(e);
   if (const char* e = getenv("GPC_DUAL")) gpc::g_dual_launch = atoi(e) != 0;
@@ -2334,19 +2350,31 @@ int gpc_post_append(gpc_post* po, const double* m_star, const double* sn2_star, 
                               : append_impl<float>(po, m_star, sn2_star, y_new, ok);
 }
 
-int gpc_post_recompute(gpc_post* po, int cnt, const int* idx, const double* hyp_cov, const double* m,
-                       const double* sn2, int sn2_is_vector, double* sn2_mult, int* L_chol, int* info) {
+int gpc_post_append_K(gpc_post* po, const double* Ks, const double* kss, const double* m_star,
+                      const double* sn2_star, double y_new, int* ok) {
   if (!po) return -2;
   gpc_ctx* c = po->ctx;
-  if (cnt <= 0 || !idx || !hyp_cov || !m || !sn2 || !sn2_mult || !L_chol || !info)
-    FAIL(c, "gpc_post_recompute: bad arguments");
+  if (!Ks || !kss || !m_star || !sn2_star || !ok) FAIL(c, "gpc_post_append_K: null argument");
+  if (po->cd.kind >= 0) FAIL(c, "gpc_post_append_K: this posterior was built from a device kernel; use gpc_post_append");
+  HIPCHK(c, hipSetDevice(c->device));
+  return po->dtype == GPC_F64 ? append_impl<double>(po, m_star, sn2_star, y_new, ok, Ks, kss)
+                              : append_impl<float>(po, m_star, sn2_star, y_new, ok, Ks, kss);
+}
+
+namespace {
+// full recompute of the listed samples of a resident posterior set, in place (device kernel: hyp_cov; K-mode: K)
+int recompute_impl(gpc_post* po, int cnt, const int* idx, const double* hyp_cov, const double* K, const double* m,
+                   const double* sn2, int sn2_is_vector, double* sn2_mult, int* L_chol, int* info) {
+  gpc_ctx* c = po->ctx;
   if (c->N != po->N || c->D != po->D) FAIL(c, "gpc_post_recompute: the context's data do not match the posterior");
-  if (po->cd.kind < 0) FAIL(c, "gpc_post_recompute: not available for posteriors built from caller-provided K");
   for (int i = 0; i < cnt; ++i)
     if (idx[i] < 0 || idx[i] >= po->S) FAIL(c, "gpc_post_recompute: sample index out of range");
   HIPCHK(c, hipSetDevice(c->device));
   Batch b;
-  fill_batch(c, b, po->cd.kind, po->cd.degree, cnt, hyp_cov, m, sn2, sn2_is_vector);
+  if (K)
+    fill_batch(c, b, -1, 0, cnt, nullptr, m, sn2, sn2_is_vector);
+  else
+    fill_batch(c, b, po->cd.kind, po->cd.degree, cnt, hyp_cov, m, sn2, sn2_is_vector);
   gpc_post tmp;
   tmp.ctx = c;
   tmp.dtype = po->dtype;
@@ -2356,8 +2384,9 @@ int gpc_post_recompute(gpc_post* po, int cnt, const int* idx, const double* hyp_
   tmp.npad = c->npad;
   tmp.cd = b.cd;
   if (tmp.npad != po->npad) FAIL(c, "gpc_post_recompute: padded size mismatch");
-  int rc = (po->dtype == GPC_F64) ? post_impl<double>(c, b, &tmp, sn2_mult, L_chol, info)
-                                  : post_impl<float>(c, b, &tmp, sn2_mult, L_chol, info);
+  KArgs km{K, nullptr, nullptr};
+  int rc = (po->dtype == GPC_F64) ? post_impl<double>(c, b, &tmp, sn2_mult, L_chol, info, K ? &km : nullptr)
+                                  : post_impl<float>(c, b, &tmp, sn2_mult, L_chol, info, K ? &km : nullptr);
   if (rc == 0) {
     const size_t w = po->dtype == GPC_F64 ? 8 : 4, msz = (size_t)po->npad * po->npad * w;
     for (int i = 0; i < cnt && rc == 0; ++i) {
@@ -2390,6 +2419,27 @@ int gpc_post_recompute(gpc_post* po, int cnt, const int* idx, const double* hyp_
   c->pool_give(tmp.W);
   c->pool_give(tmp.alpha);
   return rc;
+}
+}  // namespace
+
+int gpc_post_recompute(gpc_post* po, int cnt, const int* idx, const double* hyp_cov, const double* m,
+                       const double* sn2, int sn2_is_vector, double* sn2_mult, int* L_chol, int* info) {
+  if (!po) return -2;
+  gpc_ctx* c = po->ctx;
+  if (cnt <= 0 || !idx || !hyp_cov || !m || !sn2 || !sn2_mult || !L_chol || !info)
+    FAIL(c, "gpc_post_recompute: bad arguments");
+  if (po->cd.kind < 0) FAIL(c, "gpc_post_recompute: this posterior was built from caller-provided K; use gpc_post_recompute_K");
+  return recompute_impl(po, cnt, idx, hyp_cov, nullptr, m, sn2, sn2_is_vector, sn2_mult, L_chol, info);
+}
+
+int gpc_post_recompute_K(gpc_post* po, int cnt, const int* idx, const double* K, const double* m, const double* sn2,
+                         int sn2_is_vector, double* sn2_mult, int* L_chol, int* info) {
+  if (!po) return -2;
+  gpc_ctx* c = po->ctx;
+  if (cnt <= 0 || !idx || !K || !m || !sn2 || !sn2_mult || !L_chol || !info)
+    FAIL(c, "gpc_post_recompute_K: bad arguments");
+  if (po->cd.kind >= 0) FAIL(c, "gpc_post_recompute_K: this posterior was built from a device kernel; use gpc_post_recompute");
+  return recompute_impl(po, cnt, idx, nullptr, K, m, sn2, sn2_is_vector, sn2_mult, L_chol, info);
 }
 
 int gpc_predict(gpc_post* po, const double* xstar, int M, double* fmu, double* fs2) {
@@ -2465,7 +2515,7 @@ int gpc_set_option(gpc_ctx* c, const char* name, int value) {
   } else if (n == "leaf_fault")  // test hook: the pipelined leaf runs with a missing wave, its hand-offs time out
     gpc::g_leaf_fault = value != 0;
   else if (n == "nll_block")  // NLL-only: largest diagonal block with an inverse (multiple of 128; 0: left children inverted)
-    c->nll_block = value <= 0 ? 0 : std::max(TILE, (value / TILE) * TILE);
+    c->nll_block = value < 0 ? -1 : (value == 0 ? 0 : std::max(TILE, (value / TILE) * TILE));
   else if (n == "stable")  // every factorization in stable mode (refined panel solves, plan.h), not only the jitter retries
     c->stable = value != 0;
   else if (n == "check_queues")  // debug: verify the tile queues of persistent launches after every pipeline

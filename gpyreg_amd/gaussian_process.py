@@ -793,23 +793,31 @@ class GP:
         rank_one = (X_new is not None and y_new is not None and compute_posterior
                     and self.X is not None and self.y is not None and X_new.shape[0] == 1
                     and y_new.shape[0] == 1 and s2_new is None and hyp is None
-                    and self.s2 is None and self._post_handle is not None and self._builtin
-                    and self._post_range is None)  # sharded posteriors: recompute (every rank in step)
+                    and self.s2 is None and self.posteriors is not None
+                    and (self._post_handle is not None or self._post_range is not None))
         append_args = None
         if rank_one:
             cov_N, noise_N, mean_N = self._counts()
             m_star, sn2_star = [], []
             local_posts, first = self._local_posteriors()
+            # per-point noise: the append formulas do not apply.  Decided on a record EVERY rank holds (a rank of a
+            # sharded set may have no local posterior), so that all ranks take the same path
+            if not np.isscalar(self.noise.compute(self.posteriors[0].hyp[cov_N:cov_N + noise_N], X_new, y_new, 0)):
+                rank_one, local_posts = False, []
             for p in local_posts:
                 h = p.hyp
                 sn2 = self.noise.compute(h[cov_N:cov_N + noise_N], X_new, y_new, 0)
-                if not np.isscalar(sn2):
-                    rank_one = False  # per-point noise: the append formulas do not apply
-                    break
                 sn2_star.append(float(sn2))
                 m_star.append(float(np.ravel(self.mean.compute(
                     h[cov_N + noise_N:cov_N + noise_N + mean_N], X_new))[0]))
             append_args = (m_star, sn2_star, float(y_new[0, 0]))
+            if rank_one and not self._builtin and local_posts:
+                # a user-defined covariance object supplies its own cross covariances, like the reference's
+                # rank-one path does whatever the object is (gaussian_process.py:771-772)
+                Ks = np.stack([np.ravel(self.covariance.compute(p.hyp[0:cov_N], self.X, X_new)) for p in local_posts])
+                kss = np.array([float(np.ravel(self.covariance.compute(p.hyp[0:cov_N], X_new, compute_diag=True))[0])
+                                for p in local_posts])
+                append_args = (Ks, kss) + append_args
 
         if X_new is not None:
             self.X = X_new if self.X is None else np.concatenate((self.X, X_new))
@@ -819,23 +827,7 @@ class GP:
             self.s2 = s2_new if self.s2 is None else np.concatenate((self.s2, s2_new))
 
         if rank_one:
-            self._ctx()  # uploads the extended X, y
-            ok = self._post_handle.append(*append_args)
-            redo = np.flatnonzero(~ok)
-            if redo.size:  # unstable for these posteriors only: full update of exactly those (:789-798, :866-869)
-                cov_N, _, _ = self._counts()
-                hyp_r = np.stack([local_posts[i].hyp for i in redo])
-                pv = self._plugin_values(hyp_r, False)
-                mult, lchol, info = self._post_handle.recompute(redo, hyp_r[:, :cov_N], pv["m"], pv["sn2"], pv["vec"])
-                if np.any(info != 0):
-                    raise LinAlgError("Singular matrix for L Cholesky decomposition")
-                for k, i in enumerate(redo):
-                    m = mult[k]
-                    local_posts[i].sn2_mult = int(m) if m < 2**62 else m
-                    local_posts[i].L_chol = bool(lchol[k])
-            for p in self.posteriors:  # cached host copies are stale; refetch lazily
-                p._alpha = p._sW = p._L = None
-                p._have = {"alpha": False, "sW": False, "L": False}
+            self._append_point(local_posts, append_args, X_new, y_new)
             return
 
         if hyp is None:
@@ -848,6 +840,44 @@ class GP:
         else:
             for i in range(s_N):
                 self.posteriors[i] = Posterior(hyp[i, :], None, None, None, None, None)
+
+    def _append_point(self, local_posts, append_args, X_new, y_new):
+        """The rank-one path on this rank's posteriors (all of them unless the set is sharded): append on the device,
+        recompute alone the ones whose append is unstable (``sqrt_arg <= 0``, :789-798, :866-869), then -- under a
+        process group -- exchange (sn2_mult, L_chol, failed) so that every rank updates its records or raises alike."""
+        cov_N, _, _ = self._counts()
+        S = self.posteriors.size
+
+        def local(lo, hi):
+            if not local_posts:
+                return np.zeros((0, 2)), np.zeros(0, bool)
+            self._ctx()  # uploads the extended X, y
+            h = self._post_handle
+            ok = h.append(*append_args) if self._builtin else h.append_K(*append_args)
+            rows = np.array([[float(p.sn2_mult), float(p.L_chol)] for p in local_posts])
+            bad = np.zeros(len(local_posts), bool)
+            redo = np.flatnonzero(~ok)
+            if redo.size:  # unstable for these posteriors only: full update of exactly those
+                hyp_r = np.stack([local_posts[i].hyp for i in redo])
+                pv = self._plugin_values(hyp_r, False)
+                K = None if self._builtin else self._user_cov(hyp_r[:, :cov_N], False)[0]
+                mult, lchol, info = h.recompute(redo, hyp_r[:, :cov_N], pv["m"], pv["sn2"], pv["vec"], K=K)
+                rows[redo, 0], rows[redo, 1] = mult, lchol
+                bad[redo] = info != 0
+            return rows, bad
+
+        if self._post_range is not None:
+            full, bad = _sh.gather_rows(S, 2, local, self.process_group, _sh.fingerprint(X_new, y_new))
+        else:
+            full, bad = local(0, S)
+        if np.any(bad):
+            raise LinAlgError("Singular matrix for L Cholesky decomposition")
+        for i, p in enumerate(self.posteriors):
+            m = full[i, 0]
+            p.sn2_mult = int(m) if m < 2**62 else m
+            p.L_chol = bool(full[i, 1])
+            p._alpha = p._sW = p._L = None  # cached host copies are stale; refetched lazily
+            p._have = {"alpha": False, "sW": False, "L": False}
 
     def _compute_posteriors(self, hyp):
         """S x ``__core_computation(hyp, 0, 0)`` (reference :876-879) in one batch.  Under a process

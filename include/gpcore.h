@@ -148,6 +148,15 @@ int gpc_post_append(gpc_post* post, const double* m_star, const double* sn2_star
  * one row per listed sample.                                                                      */
 int gpc_post_recompute(gpc_post* post, int cnt, const int* idx, const double* hyp_cov, const double* m,
                        const double* sn2, int sn2_is_vector, double* sn2_mult, int* L_chol, int* info);
+/* The same two steps for a posterior set built from caller-provided covariances (gpc_posterior_batch_K): the
+ * reference's rank-one path calls self.covariance.compute whatever the object is (gaussian_process.py:771-772),
+ * so the caller hands over what that call returns.  Ks: S x n (row s = k_s(X_old, x_new), the n = N - 1 points the
+ * posterior was built on; gpc_set_data has been called with the extended X, y), kss: S (k_s(x_new, x_new)).
+ * gpc_post_recompute_K: K = cnt x N x N matrices of the listed samples on the extended data.              */
+int gpc_post_append_K(gpc_post* post, const double* Ks, const double* kss, const double* m_star,
+                      const double* sn2_star, double y_new, int* ok);
+int gpc_post_recompute_K(gpc_post* post, int cnt, const int* idx, const double* K, const double* m,
+                         const double* sn2, int sn2_is_vector, double* sn2_mult, int* L_chol, int* info);
 
 /* ---- GP.predict_full (gaussian_process.py:1603-1650) -------------------------------------
  * fmu[j*S + s] = Ks^T alpha;  cov[s] (M x M, row-major) = K** - V^T V  or  K** + Ks^T (L Ks)

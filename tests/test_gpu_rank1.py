@@ -167,3 +167,59 @@ def test_rank_one_not_applicable_falls_back_to_full_recompute():
     hc = c._post_handle
     c.update(X_new=X[20:22], y_new=y[20:22])
     assert c._post_handle is not hc and c.posteriors[0].alpha.shape == (22, 1)
+
+
+def test_rank_one_appends_with_a_user_defined_kernel_match_the_reference():
+    """The reference's rank-one path calls ``self.covariance.compute`` whatever the object is
+    (gaussian_process.py:771-772).  A Python SE kernel (no device code: K and the cross covariances come from its own
+    compute(), gpc_posterior_batch_K / gpc_post_append_K) must reproduce the reference's rank-one results of the
+    built-in SE fixtures: predictions after each of three appended points and alpha / sW / L after the last, 1e-8;
+    and a posterior declared unstable is recomputed alone from the object's own K (gpc_post_recompute_K)."""
+    import gpyreg_amd as gpr
+    from gpyreg_amd import _lib
+    from test_gpu_user_kernel import PySquaredExponential
+
+    g = _golden()
+    ran = 0
+    for name in g["names"]:
+        tag, model, N, D, flav = _parse(name)
+        if model["kernel"] != "se" or model["noise"] != (1, 0, 0):
+            continue
+        ran += 1
+        Mean = {"const": gpr.mean_functions.ConstantMean, "negquad": gpr.mean_functions.NegativeQuadratic,
+                "zero": gpr.mean_functions.ZeroMean}[model["mean"]]
+        X, y, hyp, xs = g[tag + "_X"], g[tag + "_y"], g[tag + "_hyp"], g[tag + "_xs"]
+        Xn, yn = g[tag + "_Xn"], g[tag + "_yn"]
+        gp = gpr.GP(D, PySquaredExponential(), Mean(), gpr.noise_functions.GaussianNoise(constant_add=True))
+        assert not gp._builtin
+        gp.update(X_new=X, y_new=y, hyp=hyp)
+        h0 = gp._post_handle
+        for k in range(3):
+            gp.update(X_new=Xn[k:k + 1], y_new=yn[k:k + 1])
+            assert gp._post_handle is h0, (name, "the resident posteriors must be extended, not rebuilt")
+            mu, s2 = gp.predict(xs, separate_samples=True)
+            rm, rs = g[tag + f"_mu{k}"], g[tag + f"_s2{k}"]
+            assert np.abs(mu - rm).max() <= 1e-8 * max(1.0, np.abs(rm).max()), (name, k, "mu")
+            assert np.abs(s2 - rs).max() <= 1e-8 * max(1.0, np.abs(rs).max()), (name, k, "s2")
+        for s, p in enumerate(gp.posteriors):
+            ra = g[tag + "_alpha"][s]
+            assert np.abs(p.alpha[:, 0] - ra).max() <= 1e-8 * np.abs(ra).max(), (name, s, "alpha")
+            assert np.allclose(p.sW[:, 0], g[tag + "_sW"][s], rtol=1e-12), (name, s, "sW")
+            _check_L(p, g, tag, s, 1e-8)
+        # the per-posterior fallback with the object's own K
+        gp2 = gpr.GP(D, PySquaredExponential(), Mean(), gpr.noise_functions.GaussianNoise(constant_add=True))
+        gp2.update(X_new=X, y_new=y, hyp=hyp)
+        ctx = _lib.context(0)
+        ctx.set_option("append_fail_mask", 0b010)
+        try:
+            gp2.update(X_new=Xn[:1], y_new=yn[:1])
+        finally:
+            ctx.set_option("append_fail_mask", 0)
+        X1, y1 = np.concatenate([X, Xn[:1]]), np.concatenate([y, yn[:1]])
+        full = orc.posteriors(model, hyp, X1, y1, None)
+        p1 = gp2.posteriors[1]
+        assert np.abs(p1.alpha - full[1].alpha).max() <= 1e-8 * np.abs(full[1].alpha).max(), name
+        assert np.abs(np.asarray(p1.L) - full[1].L).max() <= 1e-8 * np.abs(full[1].L).max(), name
+        mu, s2 = gp2.predict(xs, separate_samples=True)
+        assert np.abs(mu - g[tag + "_mu0"]).max() <= 1e-7 * max(1.0, np.abs(g[tag + "_mu0"]).max()), name
+    assert ran >= 2

@@ -267,6 +267,6 @@ def test_nll_only_blocked_solves_every_block_size(ctx):
                         for k, srow in enumerate(g["cfg3_rows"]):
                             assert abs(n0[srow] - g["cfg3_nlZ"][k]) < 1e-8 * abs(g["cfg3_nlZ"][k]), (blk, srow)
     finally:
-        ctx.set_option("nll_block", 1024)
+        ctx.set_option("nll_block", -1)
         ctx.set_option("stable", 0)
         bench.CONFIGS[3] = bench_cfg

@@ -68,6 +68,25 @@ def _worker(rank, world, port, q):
                 local_alpha=bool(all((gp.posteriors[i].alpha is not None) == (lo <= i < hi) for i in range(S))),
                 alpha_eq=bool(all(np.array_equal(gp.posteriors[i].alpha, ref.posteriors[i].alpha) for i in range(lo, hi))),
             )
+        # a one-point update of a SHARDED posterior set: every rank appends to its own block in O(N^2) (the handle
+        # survives), results equal the unsharded rank-one update bit for bit
+        X, y, hyp = bench.synthetic_problem(3, 5)
+        xs = X[:40] + 0.05
+        ref = bench.make_gp(3, "f64")
+        ref.shard = False
+        ref.update(X_new=X[:-1], y_new=y[:-1], hyp=hyp)
+        ref.update(X_new=X[-1:], y_new=y[-1:])
+        gp = bench.make_gp(3, "f64")
+        gp.update(X_new=X[:-1], y_new=y[:-1], hyp=hyp)
+        h0 = gp._post_handle
+        gp.update(X_new=X[-1:], y_new=y[-1:])
+        mu, s2 = gp.predict(xs, separate_samples=True)
+        rmu, rs2 = ref.predict(xs, separate_samples=True)
+        lo, hi = sharding.shard_bounds(5, rank, world)
+        out["rank1"] = dict(
+            kept=bool(gp._post_handle is h0 and gp._post_range == (lo, hi, 5) and gp._post_handle.N == X.shape[0]),
+            pred=bool(np.array_equal(mu, rmu) and np.array_equal(s2, rs2)),
+            alpha=bool(all(np.array_equal(gp.posteriors[i].alpha, ref.posteriors[i].alpha) for i in range(lo, hi))))
         # one shard holds a sample that stays non-PD after 10 escalations: EVERY rank raises, nobody hangs
         X, y, hyp = bench.synthetic_problem(3, 4)
         gp = bench.make_gp(3, "f64")
@@ -118,6 +137,7 @@ def test_sharded_gp_equals_unsharded_bitwise_two_ranks_one_gpu():
         assert "exception" not in r, r.get("exception")
         for S in (5, 16):
             assert all(r[S].values()), (rank, S, sorted(k for k, v in r[S].items() if not v))
+        assert all(r["rank1"].values()), (rank, r["rank1"])
         assert r["err"] in ("LinAlgError", "ShardError"), r["err"]
         assert r["mismatch"] is True, r["mismatch"]
         assert r["after"]

@@ -25,4 +25,4 @@ for cfg, N, S in ((3, 4096, 16), (3, 4096, 1), (2, 2048, 1), (3, 2048, 16), (2, 
         dt = (time.perf_counter() - t0) / reps
         print(f"cfg{cfg} N={N} S={S} nll_block={blk:5d}: {dt*1e3:8.3f} ms per batch, {S/dt:9.1f} evals/s, "
               f"{S*N**3/3/dt/1e12:6.2f} TFLOP/s algorithmic", flush=True)
-ctx.set_option("nll_block", 1024)
+ctx.set_option("nll_block", -1)
