@@ -284,11 +284,13 @@ struct gpc_ctx {
   bool cu_map_ok = false;
   DevBuf rsv_tbl;
   // NLL-only evaluations: largest diagonal block that gets its inverse (plan.h: potrf_nll).  0: round-2 scheme (every
-  // left child inverted); -1: automatic -- 512 when the batch is throughput-bound, S (npad/4096)^3 >= 1.5, else 0.
+  // left child inverted); -1: automatic -- 512 from npad = 2048 on, else 0.  The choice depends on the problem size
+  // ONLY, never on the batch: a row of a batch must carry the bits of its single evaluation (the speculative slice
+  // sampler relies on it, slice_sample.py), and the two schemes differ in rounding.
   // Measured (tools/nll_block_sweep.py, ms per batch at block 0 / 256 / 512 / 1024): cfg3 S=16 8.85 / 8.50 / 8.41 / 8.46;
   // N=8192 S=8 29.8 / 28.1 / 27.5 / 27.5; N=2048 S=16 1.98 / 1.95 / 1.89 / 2.00; single samples and small batches are
   // launch-bound and lose with the extra launches of the blocked solves (N=4096 S=1 2.28 / 2.42 / 2.30 / 2.28;
-  // N=2048 S=1 0.96 / 1.01 / 0.98 / 0.98; N=1000 S=8 0.52 / 0.53 / 0.54 / 0.54).
+  // N=2048 S=1 0.96 / 1.01 / 0.98 / 0.98; N=1000 S=8 0.52 / 0.53 / 0.54 / 0.54): below npad = 2048 the round-2 scheme stays.
   int nll_block = -1;
   int stable = 0;        // option: every factorization in stable mode (plan.h), not only the jitter retries
   int check_queues = 0;  // debug option: verify after every pipeline that the tile queues of its persistent launches were drained
@@ -768,7 +770,7 @@ struct Pipe {
     // NLL only: the inverse of the whole matrix is not needed (only of left children)
     const bool full_inv = (mode != MODE_NLL);
     const int nll_blk = c->nll_block >= 0 ? c->nll_block
-                                          : ((double)n * std::pow((double)npad / 4096.0, 3.0) >= 1.5 ? 512 : 0);
+                                          : (npad >= 2048 ? 512 : 0);
     const bool nll_blocked = mode == MODE_NLL && nll_blk >= TILE && npad > nll_blk;
     if (nll_blocked) {
       F.nll_block = nll_blk;
