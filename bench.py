@@ -145,7 +145,9 @@ def cpu_baseline(cfg_idx, gpu_nlz0=None, gpu_dnlz0=None):
     except Exception:  # noqa: BLE001 - the 1-thread figure is optional
         one = None
     host = _host_description()
-    blas_threads = max([b.get("num_threads") or 1 for b in host["blas"]] or [1])
+    # (the BLAS pools only: an OpenMP runtime that torch brought into the process takes no part in the oracle's work)
+    blas_threads = max([b.get("num_threads") or 1 for b in host["blas"]
+                        if b.get("internal_api") in ("openblas", "mkl", "blis", "flexiblas")] or [1])
     # `cores` = the threads the evaluation can actually use: the BLAS pool (NumPy's elementwise passes, which
     # dominate, are single-threaded); the logical CPU count is in host.logical_cpus
     out = dict(value=1.0 / med, unit="fit-evals/s", cores=blas_threads, kind="port",
