@@ -105,7 +105,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
 }
-template <typename T, bool KM, int BT, int NT>
+// AUX: cache policy of the loads (gfx940+: bit 0 sc0, bit 1 nt, bit 4 sc1); 16 = sc1, L1-bypassing loads for bytes another
+// workgroup of the SAME launch has just stored write-through (tools/seam_probe.hip; the product's kernels use 0)
+template <typename T, bool KM, int BT, int NT, int AUX = 0>
 __device__ __forceinline__ void g2r(typename MM<T>::vec_t (&r)[(BT * BKT_v<T>) / (NT * MM<T>::VEC)],
                                     __amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned pstride_bytes,
                                     unsigned voff) {
@@ -115,7 +117,7 @@ __device__ __forceinline__ void g2r(typename MM<T>::vec_t (&r)[(BT * BKT_v<T>) /
   static_assert(KM ? (NT % (BT / MM<T>::VEC) == 0) : (NT % (BKT_v<T> / MM<T>::VEC) == 0), "pass layout");
 #pragma unroll
   for (int p = 0; p < NV; ++p) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff + p * pstride_bytes, 0);
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff + p * pstride_bytes, AUX);
     r[p] = *reinterpret_cast<const vec_t*>(&v);
   }
 }
@@ -181,7 +183,10 @@ __device__ __forceinline__ void tri_tile(int tile, int& ti, int& tj) {
 // fill 256 CUs with 128-tiles).  Triangular k-ranges stay 128-granular in both.
 // NW = waves per block: 4 (2 x 2 waves of BT/2 x BT/2) or 8 (2 x 4 waves of BT/2 x BT/4:
 // half the accumulators per wave, so twice the waves per SIMD to cover staging and barriers).
-template <typename T, bool AKM, bool BKM, int BT, int NW>
+// HO ("hand-off", experiments only: tools/seam_probe.hip): operands are loaded with sc1 (L1-bypassing) loads and the
+// result is stored with agent-scope (write-through, sc1) stores, the forms MI355X_MICROARCH.md prescribes for bytes
+// that cross workgroups INSIDE one launch.
+template <typename T, bool AKM, bool BKM, int BT, int NW, int HO = 0>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const int by, T* __restrict__ smem) {
   using acc_t = typename MM<T>::acc_t;
   using vec_t = typename MM<T>::vec_t;
@@ -259,15 +264,16 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
     const __amdgpu_buffer_rsrc_t rsa = make_rsrc(AKM ? A + (size_t)k0 * g.lda + m0 : A + (size_t)m0 * g.lda + k0);
     const __amdgpu_buffer_rsrc_t rsb = make_rsrc(BKM ? B + (size_t)k0 * g.ldb + n0 : B + (size_t)n0 * g.ldb + k0);
     unsigned ua = 0, ub = 0;  // slab offsets
-    g2r<T, AKM, BT, NT>(ra, rsa, ua, psa, toa);
-    g2r<T, BKM, BT, NT>(rb, rsb, ub, psb, tob);
+    constexpr int AUX = HO ? 16 : 0;
+    g2r<T, AKM, BT, NT, AUX>(ra, rsa, ua, psa, toa);
+    g2r<T, BKM, BT, NT, AUX>(rb, rsb, ub, psb, tob);
     r2s<T, AKM, BT, NT>(smem, ra, t);
     r2s<T, BKM, BT, NT>(smem + OPSZ, rb, t);
     // slab 1 is in flight while slab 0 is multiplied (k-ranges are 128-granular: nk is a multiple of 128 / BKT >= 4)
     ua += stepa;
     ub += stepb;
-    g2r<T, AKM, BT, NT>(ra, rsa, ua, psa, toa);
-    g2r<T, BKM, BT, NT>(rb, rsb, ub, psb, tob);
+    g2r<T, AKM, BT, NT, AUX>(ra, rsa, ua, psa, toa);
+    g2r<T, BKM, BT, NT, AUX>(rb, rsb, ub, psb, tob);
     __syncthreads();
 
     // Software pipeline of one k-slab (KS k-steps of MRM x MRN MFMAs) out of LDS stage CUR.
@@ -330,8 +336,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
       if constexpr (LD) {
         ua += stepa;
         ub += stepb;
-        g2r<T, AKM, BT, NT>(ra, rsa, ua, psa, toa);
-        g2r<T, BKM, BT, NT>(rb, rsb, ub, psb, tob);
+        g2r<T, AKM, BT, NT, AUX>(ra, rsa, ua, psa, toa);
+        g2r<T, BKM, BT, NT, AUX>(rb, rsb, ub, psb, tob);
       }
       if constexpr (WR) load_frags(0, a_n, a_n + OPSZ, 0);
       mfmas(1);
@@ -380,7 +386,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
         for (int r = 0; r < 4; ++r) {
           const int row = m0 + wr * WTM + i * 16 + MM<T>::row_of(lane, r);
           const int col = n0 + wc * WTN + j * 16 + (lane & 15);
-          old[j][r] = C[(size_t)row * g.ldc + col];
+          if constexpr (HO)
+            old[j][r] = __hip_atomic_load(&C[(size_t)row * g.ldc + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else
+            old[j][r] = C[(size_t)row * g.ldc + col];
         }
     }
 #pragma unroll
@@ -395,7 +404,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
         else
           v = alpha * acc[i][j][r];
         if (g.beta) v += old[j][r];
-        C[(size_t)row * g.ldc + col] = v;
+        if constexpr (HO)
+          __hip_atomic_store(&C[(size_t)row * g.ldc + col], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else
+          C[(size_t)row * g.ldc + col] = v;
       }
   }
 }
