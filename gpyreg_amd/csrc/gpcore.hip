@@ -929,7 +929,8 @@ struct Pipe {
       }
       if (drawn != (long long)q.ntiles * q.batch) {
         qlog.clear();
-        FAIL(c, "internal error: a persistent GEMM launch ended with tiles left in its queues");
+        c->err = "internal error: a persistent GEMM launch ended with tiles left in its queues";
+        return -3;
       }
     }
     qlog.clear();

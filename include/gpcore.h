@@ -9,8 +9,10 @@
  * caller-owned host memory, row-major (C order) float64 unless stated; the library
  * copies inputs to the device and copies results back before returning.
  *
- * Return value: 0 = OK; <0 = usage or HIP error (text via gpc_last_error);
- * per-sample numerical failure is reported in info[] (>0), never as a return code.
+ * Return value: 0 = OK; -1 = HIP error, -2 = usage error, -3 = internal error (a wave hand-off inside a
+ * 128 x 128 leaf factorization timed out; the results of that call are invalid) -- text via gpc_last_error;
+ * per-sample numerical failure (a matrix that is not positive definite after the reference's ten jitter
+ * levels, gaussian_process.py:2413-2421, :2450-2453) is reported in info[] (>0), never as a return code.
  *
  * Thread-safety: one gpc_ctx per host thread / per device; calls on one ctx serialize.
  */
