@@ -268,7 +268,7 @@ struct gpc_ctx {
   static constexpr int MAXG = 8;
   hipStream_t gst[MAXG] = {};  // sample-group streams
   hipStream_t sst[MAXG + 1] = {};  // side streams of the deferred inverse products (plan.h), one per group + main
-  static constexpr int NDEV = 16;
+  static constexpr int NDEV = 64;
   hipEvent_t dev_ev[MAXG + 1][NDEV] = {};
   hipEvent_t ev_bfork[MAXG + 1] = {}, ev_btail[MAXG + 1] = {};  // split kernel build (device_section)
   // GPC_DEFER_MIN: node size from which U = T21 W11 runs on the side stream (0 off, -1 auto: the top two
@@ -292,6 +292,8 @@ struct gpc_ctx {
   // launch-bound and lose with the extra launches of the blocked solves (N=4096 S=1 2.28 / 2.42 / 2.30 / 2.28;
   // N=2048 S=1 0.96 / 1.01 / 0.98 / 0.98; N=1000 S=8 0.52 / 0.53 / 0.54 / 0.54): below npad = 2048 the round-2 scheme stays.
   int nll_block = -1;
+  // right-looking panels with look-ahead (plan.h: potrf_rl): panel height; 0 = off (the recursion)
+  int rl_panel = 0;
   int stable = 0;        // option: every factorization in stable mode (plan.h), not only the jitter retries
   int check_queues = 0;  // debug option: verify after every pipeline that the tile queues of its persistent launches were drained
   hipEvent_t ev_up = nullptr, ev_done[MAXG] = {};
@@ -709,7 +711,7 @@ struct Pipe {
       // rest as a persistent, CU-reserving launch on the side stream under the first subtree (plan.h waits
       // for it before the first launch that reads rows >= 1024).
       const int head64 = 1024 / CT, ntl_head = head64 * (head64 + 1) / 2;
-      split_build = defer_node > 0 && !c->capturing && gpc::g_persist_spare >= 0 && npad >= 2048 && reserve_tbl();
+      split_build = (defer_node > 0 || use_rl) && !c->capturing && gpc::g_persist_spare >= 0 && npad >= 2048 && reserve_tbl();
       const double* dv = c->dvec.as<double>() + (size_t)off * npad;
       if (split_build) {
         GPC_COV_DISPATCH(build_kernel, T, b.cd, dim3(ntl_head, n), dim3(256), 0, st, b.cd, (const double*)xs,
@@ -743,7 +745,7 @@ struct Pipe {
     F.info = d_info;
     F.nvalid = N;
     F.stable = stable || c->stable;
-    if (defer_node > 0 && !c->capturing && gpc::g_persist_spare >= 0) {
+    if ((defer_node > 0 || use_rl) && !c->capturing && gpc::g_persist_spare >= 0) {
       F.side = c->sst[gidx];
       F.evs = c->dev_ev[gidx];
       F.nev = gpc_ctx::NDEV;
@@ -771,8 +773,11 @@ struct Pipe {
     const bool full_inv = (mode != MODE_NLL);
     const int nll_blk = c->nll_block >= 0 ? c->nll_block
                                           : (npad >= 2048 ? 512 : 0);
-    const bool nll_blocked = mode == MODE_NLL && nll_blk >= TILE && npad > nll_blk;
-    if (nll_blocked) {
+    const bool nll_blocked = !use_rl && mode == MODE_NLL && nll_blk >= TILE && npad > nll_blk;
+    if (use_rl) {
+      F.rl_panel = c->rl_panel;
+      F.potrf_rl();
+    } else if (nll_blocked) {
       F.nll_block = nll_blk;
       F.potrf_nll(0, npad);
     } else {
@@ -792,7 +797,9 @@ struct Pipe {
     c->last_flops += F.flops;
 
     // z = L^-1 r ; quad = z.z ; alpha = W^T z / sl
-    if (nll_blocked)
+    if (use_rl)
+      F.forward_solve_rl(rvec, zvec);
+    else if (nll_blocked)
       F.forward_solve_nll(0, npad, rvec, zvec);
     else
       F.forward_solve(0, npad, full_inv, rvec, zvec);
@@ -941,6 +948,7 @@ struct Pipe {
   int chunk_s0 = 0;  // first sample (batch numbering) of the chunk being processed
   int defer_node = 0;  // plan.h: nodes at least this large run their U product on the side stream (0: none)
   bool split_build = false;
+  bool use_rl = false;  // plan.h: right-looking panels with look-ahead for this pipeline
   bool stable = false;  // plan.h: refined panel solves (jitter retries; gpc_set_option "stable")
   bool prescaled = false;  // the transfer kernel of this chunk has written the scaled inputs (run())
   int lauum_n[gpc_ctx::MAXG + 1] = {};
@@ -1053,10 +1061,12 @@ struct Pipe {
         defer_node = (npad / 2 / TILE) * TILE;
       if (defer_node > 0) groups = 1;
     }
+    // right-looking panels with look-ahead (NLL-only evaluations; side stream + CU reservation: eager)
+    use_rl = mode == MODE_NLL && c->rl_panel >= TILE && npad >= 4 * c->rl_panel && !(stable || c->stable) && !kmode();
     // Launch graphs: every one-group pipeline whose schedule lives on ONE stream (the deferred products and the split
     // build fork to side streams with CU-reserving launches and stay eager).  Round 3: up to npad = 4096 (round 2
     // stopped at 1024) -- N = 2000: 1.171 -> 1.137 ms, N = 4096: 3.03 -> 2.97 ms per single NLL+grad evaluation.
-    if (groups == 1 && defer_node == 0 && c->graph_max_npad > 0 && npad <= c->graph_max_npad && !kmode()) {
+    if (groups == 1 && defer_node == 0 && !use_rl && c->graph_max_npad > 0 && npad <= c->graph_max_npad && !kmode()) {
       int rc = graph_section(cnt);
       if (rc) return rc;
     } else if (groups == 1) {
@@ -2054,6 +2064,7 @@ int gpc_create(int device, gpc_ctx** out) {
   }
   if (const char* e = getenv("GPC_LEAF")) gpc::g_leaf_version = atoi(e) == 3 ? 3 : 5;
   if (const char* e = getenv("GPC_GRAPH_MAX_NPAD")) c->graph_max_npad = atoi(e);
+  if (const char* e = getenv("GPC_RL_PANEL")) c->rl_panel = atoi(e) <= 0 ? 0 : std::max(TILE, (atoi(e) / TILE) * TILE);
   if (const char* e = getenv("GPC_NLL_BLOCK")) c->nll_block = atoi(e) < 0 ? -1 : (atoi(e) == 0 ? 0 : std::max(TILE, (atoi(e) / TILE) * TILE));
   if (const char* e = getenv("GPC_GROUPS")) c->groups = std::max(1, std::min((int)gpc_ctx::MAXG, atoi(e)));
   if (const char* e = getenv("GPC_SMALL_BLOCKS")) gpc::g_small_launch_blocks = atoi(e);
@@ -2519,6 +2530,8 @@ int gpc_set_option(gpc_ctx* c, const char* name, int value) {
     gpc::g_leaf_fault = value != 0;
   else if (n == "nll_block")  // NLL-only: largest diagonal block with an inverse (multiple of 128; 0: left children inverted)
     c->nll_block = value < 0 ? -1 : (value == 0 ? 0 : std::max(TILE, (value / TILE) * TILE));
+  else if (n == "rl_panel")  // NLL-only: right-looking panels of this many rows with look-ahead (0: off)
+    c->rl_panel = value <= 0 ? 0 : std::max(TILE, (value / TILE) * TILE);
   else if (n == "stable")  // every factorization in stable mode (refined panel solves, plan.h), not only the jitter retries
     c->stable = value != 0;
   else if (n == "check_queues")  // debug: verify the tile queues of persistent launches after every pipeline

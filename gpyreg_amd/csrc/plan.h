@@ -291,6 +291,71 @@ struct Factor {
     forward_solve_nll(off + n1, n2, r, z);
   }
 
+  // ---- right-looking panels with one panel of look-ahead (round 3) ------------------------------------------------
+  // The recursion above exposes every latency-bound stretch of a child (its leaves, its deep-level products) on the
+  // critical path.  Here the matrix is factored in panels of `rl_panel` rows, right-looking:
+  //     D_k  potrf_inv of the diagonal block (L_kk, W_kk: the recursion above, at most rl_panel rows)
+  //     P_k  panel  L[below, k] = A[below, k] W_kk^T                                    -> scratch
+  //     N_k  trailing update of the NEXT block column only   A[below, k+1] -= L[below, k] L[k+1, k]^T
+  //     R_k  trailing update of the rest (lower tiles)       A[i, j] -= L[i, k] L[j, k]^T,  j >= k+2
+  // and R_k runs on the side stream as a CU-reserving persistent launch while D_{k+1} (latency-bound, on the reserved
+  // CUs) and P_{k+1} (which reads block column k+1 only) already proceed on the main stream; N_{k+1} joins.  The
+  // chip-filling work (sum of the R_k: almost all of the N^3/3) hides the diagonal blocks.  L below the diagonal
+  // blocks lives in the scratch, as with the recursion.
+  int rl_panel = 0;
+
+  void potrf_rl() {
+    const int P = rl_panel;
+    hipEvent_t pending = nullptr;  // join event of the R launch still in flight on the side stream
+    for (int o = 0; o < npad; o += P) {
+      const int nb = std::min(P, npad - o), rest = npad - o - nb;
+      need_rows(o + nb);
+      potrf_inv(o, nb, true, false);
+      if (rest == 0) break;
+      need_rows(npad);
+      gemm(blk(Tm, o + nb, o), sT, blk(A, o + nb, o), sA, blk(W, o, o), sW, rest, nb, nb, false, false, 1.0, 0,
+           KLO_ZERO, KHI_COL, 0);
+      const int nb2 = std::min(P, rest), rest2 = rest - nb2;
+      if (pending) {  // R_{k-1} writes the block columns N_k and R_k are about to update
+        chk(hipStreamWaitEvent(st, pending, 0));
+        pending = nullptr;
+      }
+      // N_k as a full rectangle: the tiles above the diagonal of its first block are dead writes (never read)
+      gemm(blk(A, o + nb, o + nb), sA, blk(Tm, o + nb, o), sT, blk(Tm, o + nb, o), sT, rest, nb2, nb, false, false,
+           -1.0, 1, KLO_ZERO, KHI_FULL, 0);
+      if (rest2 > 0) {
+        const int o2 = o + nb + nb2;
+        const bool ahead = side && reserve && ev_used + 2 <= nev;
+        if (ahead) {
+          hipEvent_t ev_fork = evs[ev_used++];
+          pending = evs[ev_used++];
+          chk(hipEventRecord(ev_fork, st));
+          chk(hipStreamWaitEvent(side, ev_fork, 0));
+        }
+        gemm(blk(A, o2, o2), sA, blk(Tm, o2, o), sT, blk(Tm, o2, o), sT, rest2, rest2, nb, false, false, -1.0, 1,
+             KLO_ZERO, KHI_FULL, 1, ahead ? side : nullptr, ahead ? reserve : nullptr);
+        if (ahead) chk(hipEventRecord(pending, side));
+      }
+    }
+    if (pending) chk(hipStreamWaitEvent(st, pending, 0));
+  }
+
+  // z = L^-1 r after potrf_rl: per panel, multiply by the diagonal block's inverse and eliminate with the panel below
+  void forward_solve_rl(double* r, double* z) {
+    const int P = rl_panel;
+    for (int o = 0; o < npad; o += P) {
+      const int nb = std::min(P, npad - o), rest = npad - o - nb;
+      hipLaunchKernelGGL((trmv_kernel<T>), dim3(nb / 4, batch), dim3(256), 0, st, (const T*)W, sW, npad,
+                         (const double*)r, npad, z, o);
+      ++launches;
+      if (rest > 0) {
+        hipLaunchKernelGGL((gemv_sub_kernel<T>), dim3(rest / 4, batch), dim3(256), 0, st, (const T*)Tm, sT, npad,
+                           (const double*)z, r, npad, o + nb, o, nb);
+        ++launches;
+      }
+    }
+  }
+
   // z = L^-1 r after potrf_inv(.., need_inv): blocks that own their full inverse multiply
   // by W, the others split like the factorization and eliminate with L21 (kept in A for
   // exactly those blocks).  r is consumed (updated in place); r, z: [batch][npad] doubles.

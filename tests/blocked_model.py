@@ -235,3 +235,39 @@ def forward_solve_nll(T, W, r, off, n, tile, blk):
     forward_solve_nll(T, W, r, off, n1, tile, blk)
     r[r2] -= T[r2, r1] @ r[r1]
     forward_solve_nll(T, W, r, off + n1, n2, tile, blk)
+
+
+def potrf_rl(A, W, T, npad, tile, panel, log=None):
+    """plan.h: potrf_rl -- right-looking panels (the look-ahead only reorders launches).  Per panel: D (potrf_inv of
+    the diagonal block), P (panel solve into the scratch), N (update of the next block column, a full rectangle whose
+    tiles above the diagonal are dead writes), R (lower tiles of the rest)."""
+    for o in range(0, npad, panel):
+        nb = min(panel, npad - o)
+        rest = npad - o - nb
+        info = potrf_inv(A, W, T, o, nb, tile, True, False, log)
+        if info:
+            return info
+        if rest == 0:
+            break
+        d, below = slice(o, o + nb), slice(o + nb, npad)
+        tiled_gemm(T[below, d], A[below, d], W[d, d], rest, nb, nb, tile, a_kmajor=False, b_kmajor=False, alpha=1.0,
+                   beta=0.0, khi=KHI_COL, log=log)
+        nb2 = min(panel, rest)
+        rest2 = rest - nb2
+        nxt = slice(o + nb, o + nb + nb2)
+        tiled_gemm(A[below, nxt], T[below, d], T[nxt, d], rest, nb2, nb, tile, a_kmajor=False, b_kmajor=False,
+                   alpha=-1.0, beta=1.0, log=log)
+        if rest2 > 0:
+            r2 = slice(o + nb + nb2, npad)
+            tiled_gemm(A[r2, r2], T[r2, d], T[r2, d], rest2, rest2, nb, tile, a_kmajor=False, b_kmajor=False,
+                       alpha=-1.0, beta=1.0, lower_only=True, log=log)
+    return 0
+
+
+def forward_solve_rl(T, W, r, npad, panel):
+    for o in range(0, npad, panel):
+        nb = min(panel, npad - o)
+        d, below = slice(o, o + nb), slice(o + nb, npad)
+        r[d] = np.tril(W[d, d]) @ r[d]
+        if o + nb < npad:
+            r[below] -= T[below, d] @ r[d]

@@ -171,3 +171,29 @@ def test_plan_nll_only_blocked_triangular_solves(n, tile, blk):
         bm.potrf_inv(A2, np.zeros((npad, npad)), np.zeros((npad, npad)), 0, npad, tile, False, False, old)
         assert log["flops"] < 0.97 * old["flops"]            # fewer flops than inverting every left child ...
         assert log["flops"] < 1.45 * npad**3 / 3               # ... and close to N^3/3 (+ the small inverses)
+
+
+@pytest.mark.parametrize("n,tile,panel", [(32, 4, 8), (44, 4, 8), (72, 4, 16), (64, 8, 16), (37, 4, 12), (20, 4, 4)])
+def test_plan_right_looking_panels(n, tile, panel):
+    """plan.h: potrf_rl / forward_solve_rl.  The update of the next block column is a full rectangle: its tiles above
+    the diagonal read the (never used) upper part of A -- finite junk here, as on the device -- and are dead writes."""
+    rng = np.random.default_rng(n + tile + panel)
+    A0 = _spd(n, rng)
+    A = bm.pad_identity(A0, tile)
+    npad = A.shape[0]
+    Aref = A.copy()
+    A[np.triu_indices(npad, 1)] = 12345.0  # junk, not NaN: the rectangle update reads and rewrites upper tiles
+    W = np.full((npad, npad), np.nan)
+    for o in range(0, npad, tile):
+        W[o:o + tile, o:o + tile] = 0
+    T = np.full((npad, npad), np.nan)
+    log = {}
+    assert bm.potrf_rl(A, W, T, npad, tile, panel, log) == 0
+    Lref = np.linalg.cholesky(Aref)
+    assert np.allclose(np.diag(A), np.diag(Lref), rtol=1e-12)
+    r = rng.standard_normal(npad)
+    z = r.copy()
+    bm.forward_solve_rl(T, W, z, npad, panel)
+    assert np.allclose(z, np.linalg.solve(Lref, r), rtol=1e-9, atol=1e-12)
+    if npad // panel >= 4:
+        assert log["flops"] < 1.6 * npad**3 / 3

@@ -26,3 +26,25 @@ for cfg, N, S in ((3, 4096, 16), (3, 4096, 1), (2, 2048, 1), (3, 2048, 16), (2, 
         print(f"cfg{cfg} N={N} S={S} nll_block={blk:5d}: {dt*1e3:8.3f} ms per batch, {S/dt:9.1f} evals/s, "
               f"{S*N**3/3/dt/1e12:6.2f} TFLOP/s algorithmic", flush=True)
 ctx.set_option("nll_block", -1)
+# right-looking panels with look-ahead (plan.h: potrf_rl)
+for cfg, N, S in ((3, 4096, 16), (3, 4096, 4), (3, 4096, 1), (3, 2048, 16), (5, 8192, 8), (5, 8192, 1)):
+    bench.CONFIGS[cfg] = dict(bench.CONFIGS[cfg], N=N)
+    X, y, hyp = bench.synthetic_problem(cfg, S)
+    gp = bench.make_gp(cfg, "f64")
+    gp.update(X_new=X, y_new=y, hyp=hyp[:1], compute_posterior=False)
+    ctx.set_option("rl_panel", 0)
+    ref, _ = gp.nll_batch(hyp, False)
+    for panel in (0, 256, 512, 1024):
+        if panel and N < 4 * panel:
+            continue
+        ctx.set_option("rl_panel", panel)
+        for _ in range(3):
+            got, _ = gp.nll_batch(hyp, False)
+        reps = 10
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            gp.nll_batch(hyp, False)
+        dt = (time.perf_counter() - t0) / reps
+        print(f"cfg{cfg} N={N} S={S} rl_panel={panel:5d}: {dt*1e3:8.3f} ms per batch, {S/dt:9.1f} evals/s, "
+              f"{S*N**3/3/dt/1e12:6.2f} TFLOP/s algorithmic; max rel diff to the recursion {np.abs(got/ref-1).max():.1e}", flush=True)
+ctx.set_option("rl_panel", 0)
