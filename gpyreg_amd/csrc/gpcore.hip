@@ -294,6 +294,7 @@ struct gpc_ctx {
   int nll_block = -1;
   // right-looking panels with look-ahead (plan.h: potrf_rl): panel height; 0 = off (the recursion)
   int rl_panel = 0;
+  int rl_ahead_max = 8;  // look-ahead (side stream + reserved CUs) only for batches with S (npad/4096)^3 <= this
   int stable = 0;        // option: every factorization in stable mode (plan.h), not only the jitter retries
   int check_queues = 0;  // debug option: verify after every pipeline that the tile queues of its persistent launches were drained
   hipEvent_t ev_up = nullptr, ev_done[MAXG] = {};
@@ -776,6 +777,7 @@ struct Pipe {
     const bool nll_blocked = !use_rl && mode == MODE_NLL && nll_blk >= TILE && npad > nll_blk;
     if (use_rl) {
       F.rl_panel = c->rl_panel;
+      F.rl_lookahead = (double)n * std::pow((double)npad / 4096.0, 3.0) <= (double)c->rl_ahead_max;
       F.potrf_rl();
     } else if (nll_blocked) {
       F.nll_block = nll_blk;
@@ -2530,6 +2532,8 @@ int gpc_set_option(gpc_ctx* c, const char* name, int value) {
     gpc::g_leaf_fault = value != 0;
   else if (n == "nll_block")  // NLL-only: largest diagonal block with an inverse (multiple of 128; 0: left children inverted)
     c->nll_block = value < 0 ? -1 : (value == 0 ? 0 : std::max(TILE, (value / TILE) * TILE));
+  else if (n == "rl_ahead_max")  // look-ahead of the right-looking plan only up to this batch work S (npad/4096)^3
+    c->rl_ahead_max = value;
   else if (n == "rl_panel")  // NLL-only: right-looking panels of this many rows with look-ahead (0: off)
     c->rl_panel = value <= 0 ? 0 : std::max(TILE, (value / TILE) * TILE);
   else if (n == "stable")  // every factorization in stable mode (refined panel solves, plan.h), not only the jitter retries

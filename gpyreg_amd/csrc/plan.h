@@ -303,6 +303,7 @@ struct Factor {
   // chip-filling work (sum of the R_k: almost all of the N^3/3) hides the diagonal blocks.  L below the diagonal
   // blocks lives in the scratch, as with the recursion.
   int rl_panel = 0;
+  bool rl_lookahead = true;  // false: R_k on the main stream, whole chip (same arithmetic, launches in order)
 
   void potrf_rl() {
     const int P = rl_panel;
@@ -325,7 +326,7 @@ struct Factor {
            -1.0, 1, KLO_ZERO, KHI_FULL, 0);
       if (rest2 > 0) {
         const int o2 = o + nb + nb2;
-        const bool ahead = side && reserve && ev_used + 2 <= nev;
+        const bool ahead = rl_lookahead && side && reserve && ev_used + 2 <= nev;
         if (ahead) {
           hipEvent_t ev_fork = evs[ev_used++];
           pending = evs[ev_used++];

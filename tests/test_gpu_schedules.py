@@ -270,3 +270,43 @@ def test_nll_only_blocked_solves_every_block_size(ctx):
         ctx.set_option("nll_block", -1)
         ctx.set_option("stable", 0)
         bench.CONFIGS[3] = bench_cfg
+
+
+def test_right_looking_panels_with_lookahead_opt_in(ctx):
+    """gpc_set_option("rl_panel", 512): NLL-only evaluations factored right-looking in panels with one panel of
+    look-ahead (plan.h: potrf_rl; the trailing update of panel k on a CU-reserving side-stream launch while the next
+    diagonal block is factored).  Same result as the recursion to rounding and as the reference to 1e-8; the look-ahead
+    only reorders launches: with and without it the bits are the same, and a row of a batch equals its single
+    evaluation.  Off by default (it pays for one to four samples at N >= 4096 only: DESIGN.md section 9)."""
+    import bench
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fullsize_cases.npz"), allow_pickle=False)
+    bench_cfg = dict(bench.CONFIGS[3])
+    try:
+        for N, S in ((2304, 3), (4096, 4)):
+            bench.CONFIGS[3] = dict(bench_cfg, N=N)
+            X, y, hyp = bench.synthetic_problem(3, S)
+            gp = bench.make_gp(3, "f64")
+            gp.update(X_new=X, y_new=y, hyp=hyp[:1], compute_posterior=False)
+            ctx.set_option("rl_panel", 0)
+            ref, _ = gp.nll_batch(hyp, compute_grad=False)
+            ctx.set_option("check_queues", 1)
+            for panel in (256, 512):
+                ctx.set_option("rl_panel", panel)
+                res = []
+                for ahead in (1000, 0):
+                    ctx.set_option("rl_ahead_max", ahead)
+                    res.append(gp.nll_batch(hyp, compute_grad=False)[0])
+                    one, _ = gp.nll_batch(hyp[S - 1:S], compute_grad=False)
+                    assert one[0] == res[-1][S - 1]
+                assert np.array_equal(res[0], res[1]), (N, panel, "the look-ahead changed a bit")
+                assert np.abs(res[0] - ref).max() <= 1e-12 * np.abs(ref).max(), (N, panel)
+                if N == 4096:
+                    for k, srow in enumerate(g["cfg3_rows"]):
+                        if srow < S:
+                            assert abs(res[0][srow] - g["cfg3_nlZ"][k]) < 1e-8 * abs(g["cfg3_nlZ"][k])
+    finally:
+        ctx.set_option("check_queues", 0)
+        ctx.set_option("rl_panel", 0)
+        ctx.set_option("rl_ahead_max", 8)
+        bench.CONFIGS[3] = bench_cfg
