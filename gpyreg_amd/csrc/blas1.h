@@ -62,13 +62,16 @@ constexpr int TRC = 128;  // = TILE, so every padded size is a whole number of c
 // Each lane owns VEC adjacent columns (one 16-byte load per row), each wave every fourth row of the chunk,
 // eight loads in flight per lane.   grid = (npad / (64 * VEC), npad / TRC, batch)
 // quad != nullptr: block (0, 0, b) also leaves z[b] . z[b] there -- the arithmetic of dot_kernel, without its launch.
-template <typename T>
-__global__ __launch_bounds__(256) void trmv_t_part_kernel(const T* __restrict__ W_all, long long sW, int ldw,
-                                                          const double* __restrict__ z_all, int npad,
-                                                          double* __restrict__ part_all, double* __restrict__ quad) {
+// UNR = loads in flight per lane: 8 when the kernel has the chip to itself; 1 (trmv_t_part_low_kernel, <= 32 VGPRs)
+// for the launch that runs UNDER the W^T W GEMM (gpcore.hip: solves beside lauum), whose two resident blocks per CU
+// leave 32 VGPRs per lane: the rows are added in the same order for every UNR, so the result does not depend on it.
+template <typename T, int UNR>
+__device__ __forceinline__ void trmv_t_part_body(const T* __restrict__ W_all, long long sW, int ldw,
+                                                 const double* __restrict__ z_all, int npad,
+                                                 double* __restrict__ part_all, double* __restrict__ quad,
+                                                 double (*red)[64 * MM<T>::VEC]) {
   using vec_t = typename MM<T>::vec_t;
   constexpr int VEC = MM<T>::VEC;
-  __shared__ double red[4][64 * VEC];
   const int b = blockIdx.z, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (quad && blockIdx.x == 0 && blockIdx.y == 0) {
     const double* zz = z_all + (size_t)b * npad;
@@ -92,12 +95,12 @@ __global__ __launch_bounds__(256) void trmv_t_part_kernel(const T* __restrict__ 
 #pragma unroll
   for (int e = 0; e < VEC; ++e) s[e] = 0.0;
   int i = istart + w;
-  for (; i + 28 < r1; i += 32) {
-    vec_t v[8];
+  for (; i + 4 * (UNR - 1) < r1; i += 4 * UNR) {
+    vec_t v[UNR];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const vec_t*>(Wb + (size_t)(i + 4 * u) * ldw + k);
+    for (int u = 0; u < UNR; ++u) v[u] = *reinterpret_cast<const vec_t*>(Wb + (size_t)(i + 4 * u) * ldw + k);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < UNR; ++u) {
       const double zi = z[i + 4 * u];
 #pragma unroll
       for (int e = 0; e < VEC; ++e) s[e] += lane_ok ? (double)v[u][e] * zi : 0.0;
@@ -114,6 +117,21 @@ __global__ __launch_bounds__(256) void trmv_t_part_kernel(const T* __restrict__ 
   for (int q = threadIdx.x; q < 64 * VEC; q += 256)
     if (blockIdx.x * 64 * VEC + q < npad)
       part_all[((size_t)b * nch + blockIdx.y) * npad + blockIdx.x * 64 * VEC + q] = red[0][q] + red[1][q] + red[2][q] + red[3][q];
+}
+template <typename T, int UNR = 8>
+__global__ __launch_bounds__(256) void trmv_t_part_kernel(const T* __restrict__ W_all, long long sW, int ldw,
+                                                          const double* __restrict__ z_all, int npad,
+                                                          double* __restrict__ part_all, double* __restrict__ quad) {
+  __shared__ double red[4][64 * MM<T>::VEC];
+  trmv_t_part_body<T, UNR>(W_all, sW, ldw, z_all, npad, part_all, quad, red);
+}
+// the form that fits beside two resident 128-tile GEMM blocks per CU: at most 32 VGPRs, one load in flight per lane
+template <typename T>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(32))) void trmv_t_part_low_kernel(
+    const T* __restrict__ W_all, long long sW, int ldw, const double* __restrict__ z_all, int npad,
+    double* __restrict__ part_all, double* __restrict__ quad) {
+  __shared__ double red[4][64 * MM<T>::VEC];
+  trmv_t_part_body<T, 1>(W_all, sW, ldw, z_all, npad, part_all, quad, red);
 }
 
 // grid = (npad/128, batch), 128 threads; scale[b] = 1/sp[b][sp_off] when sp != nullptr

@@ -293,6 +293,7 @@ struct gpc_ctx {
   // N=2048 S=1 0.96 / 1.01 / 0.98 / 0.98; N=1000 S=8 0.52 / 0.53 / 0.54 / 0.54): below npad = 2048 the round-2 scheme stays.
   int nll_block = -1;
   // right-looking panels with look-ahead (plan.h: potrf_rl): panel height; 0 = off (the recursion)
+  int solves_beside_lauum = 1;  // option: the two triangular mat-vecs of a gradient evaluation run under the W^T W launch
   int rl_panel = 0;
   int rl_ahead_max = 8;  // look-ahead (side stream + reserved CUs) only for batches with S (npad/4096)^3 <= this
   int stable = 0;        // option: every factorization in stable mode (plan.h), not only the jitter retries
@@ -749,7 +750,7 @@ struct Pipe {
     if ((defer_node > 0 || use_rl) && !c->capturing && gpc::g_persist_spare >= 0) {
       F.side = c->sst[gidx];
       F.evs = c->dev_ev[gidx];
-      F.nev = gpc_ctx::NDEV;
+      F.nev = gpc_ctx::NDEV - 2;  // (the last two belong to the solves beside W^T W)
       F.defer_min = defer_node;
       F.reserve = reserve_tbl();
     }
@@ -785,7 +786,54 @@ struct Pipe {
     } else {
       F.potrf_inv(0, npad, full_inv, mode == MODE_POST);
     }
+    // z = L^-1 r ; quad = z.z ; alpha = W^T z / sl -- two triangular matrix-vector products over W, HBM-bound and
+    // independent of W^T W.  With the gradient they run UNDER the W^T W launch (round 3): its two resident blocks per
+    // CU use 2 x 240 of the 512 VGPRs per lane and 147 of 160 KB of LDS, so kernels of at most 32 VGPRs (trmv_kernel:
+    // 20; trmv_t_part_low_kernel: 32, see blas1.h) are dispatched beside them and take their bytes while the GEMM is
+    // MFMA-bound; forked on the side stream just before the launch, joined before the gradient contraction, which
+    // needs alpha.  (Eager one- or multi-group pipelines; a captured graph keeps the serial order.)
+    // (fp64 only: the fp32 GEMM uses 249 VGPRs, two of its blocks leave no register for anything else)
+    const bool solves_beside_lauum = mode == MODE_GRAD && !c->capturing && !kmode() && c->solves_beside_lauum &&
+                                     sizeof(T) == 8 && npad >= 2048 && gpc::g_persist_spare >= 0;
+    auto solves = [&](hipStream_t sx) -> int {
+      const hipStream_t keep = F.st;
+      F.st = sx;
+      if (use_rl)
+        F.forward_solve_rl(rvec, zvec);
+      else if (nll_blocked)
+        F.forward_solve_nll(0, npad, rvec, zvec);
+      else
+        F.forward_solve(0, npad, full_inv, rvec, zvec);
+      F.st = keep;
+      if (mode == MODE_NLL) {
+        hipLaunchKernelGGL(dot_kernel, dim3(1, n), dim3(256), 0, sx, (const double*)zvec, (const double*)zvec,
+                           npad, npad, d_quad);
+      } else {  // quad = z.z rides in the first block of the transposed product
+        double* tpart = c->tpart.as<double>() + (size_t)off * (npad / TRC) * npad;
+        const dim3 gt((npad + 64 * MM<T>::VEC - 1) / (64 * MM<T>::VEC), npad / TRC, n);
+        if (sx != st)
+          hipLaunchKernelGGL((trmv_t_part_low_kernel<T>), gt, dim3(256), 0, sx, (const T*)Wc, sM, npad, (const double*)zvec,
+                             npad, tpart, d_quad);
+        else
+          hipLaunchKernelGGL((trmv_t_part_kernel<T, 8>), gt, dim3(256), 0, sx, (const T*)Wc, sM, npad, (const double*)zvec,
+                             npad, tpart, d_quad);
+        hipLaunchKernelGGL(trmv_t_sum_kernel, dim3(npad / 128, n), dim3(128), 0, sx, (const double*)tpart, npad,
+                           (const double*)spb, (int)SP_STRIDE, (int)SP_SL, avec);
+      }
+      HIPCHK(c, hipGetLastError());
+      return 0;
+    };
+    hipEvent_t ev_solved = nullptr;
     if (mode == MODE_GRAD) {
+      if (solves_beside_lauum) {
+        hipStream_t sx = c->sst[gidx];
+        hipEvent_t ev_fork = c->dev_ev[gidx][gpc_ctx::NDEV - 1];
+        ev_solved = c->dev_ev[gidx][gpc_ctx::NDEV - 2];
+        HIPCHK(c, hipEventRecord(ev_fork, st));
+        HIPCHK(c, hipStreamWaitEvent(sx, ev_fork, 0));
+        if (int rc = solves(sx)) return rc;
+        HIPCHK(c, hipEventRecord(ev_solved, sx));
+      }
       if (!c->capturing) HIPCHK(c, hipEventRecord(c->ev_l0[gidx], st));
       F.lauum(Tc, sM);
       if (!c->capturing) {
@@ -798,23 +846,10 @@ struct Pipe {
     if (f1 && !c->capturing) HIPCHK(c, hipEventRecord(f1, st));
     c->last_flops += F.flops;
 
-    // z = L^-1 r ; quad = z.z ; alpha = W^T z / sl
-    if (use_rl)
-      F.forward_solve_rl(rvec, zvec);
-    else if (nll_blocked)
-      F.forward_solve_nll(0, npad, rvec, zvec);
-    else
-      F.forward_solve(0, npad, full_inv, rvec, zvec);
-    if (mode == MODE_NLL) {
-      hipLaunchKernelGGL(dot_kernel, dim3(1, n), dim3(256), 0, st, (const double*)zvec, (const double*)zvec,
-                         npad, npad, d_quad);
-    } else {  // quad = z.z rides in the first block of the transposed product
-      double* tpart = c->tpart.as<double>() + (size_t)off * (npad / TRC) * npad;
-      hipLaunchKernelGGL((trmv_t_part_kernel<T>), dim3((npad + 64 * MM<T>::VEC - 1) / (64 * MM<T>::VEC), npad / TRC, n), dim3(256), 0, st, (const T*)Wc,
-                         sM, npad, (const double*)zvec, npad, tpart, d_quad);
-      hipLaunchKernelGGL(trmv_t_sum_kernel, dim3(npad / 128, n), dim3(128), 0, st, (const double*)tpart, npad,
-                         (const double*)spb, (int)SP_STRIDE, (int)SP_SL, avec);
-    }
+    if (ev_solved)
+      HIPCHK(c, hipStreamWaitEvent(st, ev_solved, 0));
+    else if (int rc = solves(st))
+      return rc;
     HIPCHK(c, hipGetLastError());
 
     const int Pn = P();
@@ -2532,6 +2567,8 @@ int gpc_set_option(gpc_ctx* c, const char* name, int value) {
     gpc::g_leaf_fault = value != 0;
   else if (n == "nll_block")  // NLL-only: largest diagonal block with an inverse (multiple of 128; 0: left children inverted)
     c->nll_block = value < 0 ? -1 : (value == 0 ? 0 : std::max(TILE, (value / TILE) * TILE));
+  else if (n == "solves_beside_lauum")  // 0: the triangular mat-vecs after the W^T W launch (round-2 order)
+    c->solves_beside_lauum = value != 0;
   else if (n == "rl_ahead_max")  // look-ahead of the right-looking plan only up to this batch work S (npad/4096)^3
     c->rl_ahead_max = value;
   else if (n == "rl_panel")  // NLL-only: right-looking panels of this many rows with look-ahead (0: off)

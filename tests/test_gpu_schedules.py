@@ -310,3 +310,28 @@ def test_right_looking_panels_with_lookahead_opt_in(ctx):
         ctx.set_option("rl_panel", 0)
         ctx.set_option("rl_ahead_max", 8)
         bench.CONFIGS[3] = bench_cfg
+
+
+def test_solves_beside_the_inverse_product_do_not_change_a_bit(ctx):
+    """With the gradient the two triangular mat-vecs (z = W r, alpha = W^T z) run on the side stream UNDER the W^T W
+    launch (low-register kernels that fit beside its two resident blocks per CU): an order of launches, not of
+    arithmetic.  NLL, gradient with the overlap on (default) and off must be identical bit for bit; N = 2304 and
+    4096, one and several samples, and under the two-sample-group schedule."""
+    import bench
+
+    bench_cfg = dict(bench.CONFIGS[3])
+    try:
+        for N, S in ((2304, 1), (2304, 6), (4096, 16), (4096, 66)):
+            bench.CONFIGS[3] = dict(bench_cfg, N=N)
+            X, y, hyp = bench.synthetic_problem(3, S)
+            gp = bench.make_gp(3, "f64")
+            gp.update(X_new=X, y_new=y, hyp=hyp[:1], compute_posterior=False)
+            res = []
+            for on in (1, 0, 1):
+                ctx.set_option("solves_beside_lauum", on)
+                res.append(gp.nll_batch(hyp, compute_grad=True))
+            for r in res[1:]:
+                assert np.array_equal(res[0][0], r[0]) and np.array_equal(res[0][1], r[1]), (N, S)
+    finally:
+        ctx.set_option("solves_beside_lauum", 1)
+        bench.CONFIGS[3] = bench_cfg
