@@ -254,6 +254,8 @@ def main():
     if rank == 0 and grad:
         groups_env = int(os.environ.get("GPC_GROUPS", "2"))
         ctx.set_option("groups", 1)
+        # ... nor with the two triangular mat-vecs that the timed steps run UNDER it (they cost it ~3 %)
+        ctx.set_option("solves_beside_lauum", 0)
         gp.shard = False  # rank-local extra steps (the other ranks are not in this loop)
         for _ in range(3):
             gp.nll_batch(hyp[:S], compute_grad=True)
@@ -261,6 +263,7 @@ def main():
             lau_ms.append(lm)
         lau_ms = lau_ms[1:]
         ctx.set_option("groups", groups_env)
+        ctx.set_option("solves_beside_lauum", 1)
 
     if rank == 0:
         N = cfg["N"]

@@ -33,6 +33,68 @@ __global__ __launch_bounds__(256) void trmv_kernel(const T* __restrict__ W_all, 
   if (lane == 0) z_all[(size_t)b * npad + i] = s;
 }
 
+// The same product for the launch that runs UNDER the W^T W GEMM (gpcore.hip: solves beside lauum), where one wave of
+// at most 32 VGPRs per SIMD is all that fits beside the GEMM's two resident blocks and every load sees the latency
+// of a busy memory system: one wave takes FOUR rows at once, so four loads of W are in flight per load of r.  Per
+// row the terms are added in trmv_kernel's order: same bits.   grid = (npad/16, batch), 256 threads
+template <typename T>
+__global__ __launch_bounds__(256) void trmv_low_kernel(const T* __restrict__ W_all, long long sW, int ldw,
+                                                       const double* __restrict__ r_all, int npad,
+                                                       double* __restrict__ z_all) {
+  using vec_t = typename MM<T>::vec_t;
+  constexpr int VEC = MM<T>::VEC;
+  // everything but the lane's column offset is wave-uniform and lives in scalar registers (the budget is 32 VGPRs):
+  // four 16-byte loads in flight (16), the r values (4), four accumulators (8), the offset
+  // Beside the GEMM the wave's few fp64 FMAs compete with MFMAs for the DP pipe, and the arbiter serves the older
+  // (GEMM) waves first: without a raised priority a row took ~10 us per 128 columns.
+  __builtin_amdgcn_s_setprio(3);
+  const int b = blockIdx.y, lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int i0 = blockIdx.x * 16 + wv * 4;  // four consecutive rows: one 128-tile, one k-range
+  const T* W0 = W_all + (size_t)b * sW + (size_t)i0 * ldw;
+  const __amdgpu_buffer_rsrc_t q0 = make_rsrc(W0), q1 = make_rsrc(W0 + ldw), q2 = make_rsrc(W0 + 2 * (size_t)ldw),
+                               q3 = make_rsrc(W0 + 3 * (size_t)ldw), qr = make_rsrc(r_all + (size_t)b * npad);
+  const int kend = ((i0 >> 7) + 1) << 7;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  static_assert(sizeof(vec_t) == 16, "16-byte loads");
+  // one induction variable: the lane's byte offset into r (8 bytes per column); W's is the same (fp64) or half of it
+#pragma unroll 1
+  for (unsigned orr = lane * VEC * 8u; orr < (unsigned)kend * 8u; orr += 64 * VEC * 8u) {
+    const unsigned ow = sizeof(T) == 8 ? orr : orr >> 1;
+    const u32x4 a0 = __builtin_amdgcn_raw_buffer_load_b128(q0, ow, 0, 0);
+    const u32x4 a1 = __builtin_amdgcn_raw_buffer_load_b128(q1, ow, 0, 0);
+    const u32x4 a2 = __builtin_amdgcn_raw_buffer_load_b128(q2, ow, 0, 0);
+    const u32x4 a3 = __builtin_amdgcn_raw_buffer_load_b128(q3, ow, 0, 0);
+    const vec_t w0 = *reinterpret_cast<const vec_t*>(&a0), w1 = *reinterpret_cast<const vec_t*>(&a1),
+                w2 = *reinterpret_cast<const vec_t*>(&a2), w3 = *reinterpret_cast<const vec_t*>(&a3);
+#pragma unroll
+    for (int e = 0; e < VEC; e += 2) {  // r: 16 bytes = two doubles per load
+      const u32x4 rr = __builtin_amdgcn_raw_buffer_load_b128(qr, orr + 8u * e, 0, 0);
+      const double r0 = reinterpret_cast<const double*>(&rr)[0], r1 = reinterpret_cast<const double*>(&rr)[1];
+      s0 += (double)w0[e] * r0;
+      s1 += (double)w1[e] * r0;
+      s2 += (double)w2[e] * r0;
+      s3 += (double)w3[e] * r0;
+      s0 += (double)w0[e + 1] * r1;
+      s1 += (double)w1[e + 1] * r1;
+      s2 += (double)w2[e + 1] * r1;
+      s3 += (double)w3[e + 1] * r1;
+    }
+  }
+  s0 = wave_sum(s0);
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  s3 = wave_sum(s3);
+  // (the lane index is recomputed here so that it does not occupy a register through the loop)
+  if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) {
+    double* z = z_all + (size_t)b * npad + i0;
+    z[0] = s0;
+    z[1] = s1;
+    z[2] = s2;
+    z[3] = s3;
+  }
+}
+
 // r[b][row0 + i] -= sum_{k < ncols} A[b][row0 + i][col0 + k] * z[b][col0 + k]
 // (the off-diagonal update of the blocked forward solve).  grid = (nrows/4, batch)
 template <typename T>
@@ -62,7 +124,7 @@ constexpr int TRC = 128;  // = TILE, so every padded size is a whole number of c
 // Each lane owns VEC adjacent columns (one 16-byte load per row), each wave every fourth row of the chunk,
 // eight loads in flight per lane.   grid = (npad / (64 * VEC), npad / TRC, batch)
 // quad != nullptr: block (0, 0, b) also leaves z[b] . z[b] there -- the arithmetic of dot_kernel, without its launch.
-// UNR = loads in flight per lane: 8 when the kernel has the chip to itself; 1 (trmv_t_part_low_kernel, <= 32 VGPRs)
+// UNR = loads in flight per lane: 8 when the kernel has the chip to itself; 3 (trmv_t_part_low_kernel, <= 32 VGPRs)
 // for the launch that runs UNDER the W^T W GEMM (gpcore.hip: solves beside lauum), whose two resident blocks per CU
 // leave 32 VGPRs per lane: the rows are added in the same order for every UNR, so the result does not depend on it.
 template <typename T, int UNR>
@@ -72,7 +134,7 @@ __device__ __forceinline__ void trmv_t_part_body(const T* __restrict__ W_all, lo
                                                  double (*red)[64 * MM<T>::VEC]) {
   using vec_t = typename MM<T>::vec_t;
   constexpr int VEC = MM<T>::VEC;
-  const int b = blockIdx.z, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int b = blockIdx.z, lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (quad && blockIdx.x == 0 && blockIdx.y == 0) {
     const double* zz = z_all + (size_t)b * npad;
     double q = 0.0;
@@ -125,13 +187,14 @@ __global__ __launch_bounds__(256) void trmv_t_part_kernel(const T* __restrict__ 
   __shared__ double red[4][64 * MM<T>::VEC];
   trmv_t_part_body<T, UNR>(W_all, sW, ldw, z_all, npad, part_all, quad, red);
 }
-// the form that fits beside two resident 128-tile GEMM blocks per CU: at most 32 VGPRs, one load in flight per lane
+// the form that fits beside two resident 128-tile GEMM blocks per CU: at most 32 VGPRs, three loads in flight per lane
 template <typename T>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(32))) void trmv_t_part_low_kernel(
+__global__ __launch_bounds__(256) void trmv_t_part_low_kernel(
     const T* __restrict__ W_all, long long sW, int ldw, const double* __restrict__ z_all, int npad,
     double* __restrict__ part_all, double* __restrict__ quad) {
   __shared__ double red[4][64 * MM<T>::VEC];
-  trmv_t_part_body<T, 1>(W_all, sW, ldw, z_all, npad, part_all, quad, red);
+  __builtin_amdgcn_s_setprio(3);  // see trmv_low_kernel
+  trmv_t_part_body<T, 3>(W_all, sW, ldw, z_all, npad, part_all, quad, red);
 }
 
 // grid = (npad/128, batch), 128 threads; scale[b] = 1/sp[b][sp_off] when sp != nullptr

@@ -75,6 +75,13 @@ __device__ __forceinline__ double block_sum_256(double v, double* sh4) {
   return sh4[0] + sh4[1] + sh4[2] + sh4[3];
 }
 
+// raw buffer descriptor based at `base` (no bounds: 2 GiB range, 32-bit byte offsets): loads through it take a
+// scalar descriptor + one VGPR of offset instead of a 64-bit vector address
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+
 // ---- persistent launches: tile queues and CU reservation ---------------------------------------
 constexpr int NQ = 8;  // tile queues of a persistent GEMM launch (one per XCD, gemm.h)
 // Device counters of one persistent launch: NQ tile queues, then the two counters of the CU reservation

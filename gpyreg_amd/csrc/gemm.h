@@ -101,10 +101,6 @@ __device__ __forceinline__ size_t stage_pstride(int ld) {
 // origin, the per-thread byte offset `voff` is fixed for the whole k-loop and the slab / pass
 // offsets are scalars, so the loop carries no vector address arithmetic at all
 // (241 instead of 256 VGPRs in the fp64 128-tile kernel).
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
-}
 // AUX: cache policy of the loads (gfx940+: bit 0 sc0, bit 1 nt, bit 4 sc1); 16 = sc1, L1-bypassing loads for bytes another
 // workgroup of the SAME launch has just stored write-through (tools/seam_probe.hip; the product's kernels use 0)
 template <typename T, bool KM, int BT, int NT, int AUX = 0>

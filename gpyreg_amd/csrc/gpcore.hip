@@ -788,8 +788,8 @@ struct Pipe {
     }
     // z = L^-1 r ; quad = z.z ; alpha = W^T z / sl -- two triangular matrix-vector products over W, HBM-bound and
     // independent of W^T W.  With the gradient they run UNDER the W^T W launch (round 3): its two resident blocks per
-    // CU use 2 x 240 of the 512 VGPRs per lane and 147 of 160 KB of LDS, so kernels of at most 32 VGPRs (trmv_kernel:
-    // 20; trmv_t_part_low_kernel: 32, see blas1.h) are dispatched beside them and take their bytes while the GEMM is
+    // CU use 2 x 240 of the 512 VGPRs per lane and 147 of 160 KB of LDS, so kernels of at most 32 VGPRs (trmv_low_kernel,
+    // trmv_t_part_low_kernel, blas1.h) are dispatched beside them and take their bytes while the GEMM is
     // MFMA-bound; forked on the side stream just before the launch, joined before the gradient contraction, which
     // needs alpha.  (Eager one- or multi-group pipelines; a captured graph keeps the serial order.)
     // (fp64 only: the fp32 GEMM uses 249 VGPRs, two of its blocks leave no register for anything else)
@@ -798,6 +798,7 @@ struct Pipe {
     auto solves = [&](hipStream_t sx) -> int {
       const hipStream_t keep = F.st;
       F.st = sx;
+      F.low_regs = sx != st;
       if (use_rl)
         F.forward_solve_rl(rvec, zvec);
       else if (nll_blocked)
@@ -805,6 +806,7 @@ struct Pipe {
       else
         F.forward_solve(0, npad, full_inv, rvec, zvec);
       F.st = keep;
+      F.low_regs = false;
       if (mode == MODE_NLL) {
         hipLaunchKernelGGL(dot_kernel, dim3(1, n), dim3(256), 0, sx, (const double*)zvec, (const double*)zvec,
                            npad, npad, d_quad);

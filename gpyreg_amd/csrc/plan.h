@@ -360,10 +360,15 @@ struct Factor {
   // z = L^-1 r after potrf_inv(.., need_inv): blocks that own their full inverse multiply
   // by W, the others split like the factorization and eliminate with L21 (kept in A for
   // exactly those blocks).  r is consumed (updated in place); r, z: [batch][npad] doubles.
+  bool low_regs = false;  // forward_solve of the whole matrix with the kernel that fits beside the W^T W launch
   void forward_solve(int off, int n, bool need_inv, double* r, double* z) {
     if (need_inv || n == TILE) {
-      hipLaunchKernelGGL((trmv_kernel<T>), dim3(n / 4, batch), dim3(256), 0, st, (const T*)W, sW, npad,
-                         (const double*)r, npad, z, off);
+      if (low_regs && off == 0 && n == npad)
+        hipLaunchKernelGGL((trmv_low_kernel<T>), dim3(n / 16, batch), dim3(256), 0, st, (const T*)W, sW, npad,
+                           (const double*)r, npad, z);
+      else
+        hipLaunchKernelGGL((trmv_kernel<T>), dim3(n / 4, batch), dim3(256), 0, st, (const T*)W, sW, npad,
+                           (const double*)r, npad, z, off);
       ++launches;
       return;
     }
