@@ -233,6 +233,17 @@ def test_stable_mode_is_the_same_factorization_up_to_rounding(ctx):
                 for k in (0, 1):
                     assert abs(res[1][0][k] - g["cfg3_nlZ"][k]) < 1e-8 * abs(g["cfg3_nlZ"][k])
                     assert _rel_grad(res[1][1][k], g["cfg3_dnlZ"][k]) < 1e-8
+        # fp32: the refined leaf / node products in single precision (the retries of an fp32 evaluation)
+        bench.CONFIGS[3] = dict(bench_cfg, N=700)
+        X, y, hyp = bench.synthetic_problem(3, 3)
+        out = []
+        for stable in (0, 1):
+            ctx.set_option("stable", stable)
+            gp = bench.make_gp(3, "f32")
+            gp.update(X_new=X, y_new=y, hyp=hyp)
+            out.append(gp.nll_batch(hyp, compute_grad=True) + gp.predict(X[:20] + 0.01, separate_samples=True))
+        for a, b in zip(out[0], out[1]):
+            assert np.abs(a - b).max() <= 2e-4 * max(1.0, np.abs(a).max())
     finally:
         ctx.set_option("stable", 0)
         bench.CONFIGS[3] = bench_cfg
