@@ -159,3 +159,33 @@ def test_hyperparameter_dict_roundtrip_and_order():
     assert np.isnan(gp.get_hyperparameters(as_array=True)).all()
     gp.update(hyp=arr, compute_posterior=False)
     assert np.array_equal(gp.get_hyperparameters(as_array=True), arr)
+
+
+def test_assemble_profiles_refuses_a_directory_with_two_runs(tmp_path):
+    """tools/assemble_profiles.py must not pick one of several CSVs of a pass (round 2's "r02f" set mixed two code
+    states that way): exactly one file per pass, or it stops."""
+    import shutil
+    import subprocess
+    import sys
+
+    work = tmp_path / "repo"
+    (work / "gpurun_out" / "rX" / "prof" / "a").mkdir(parents=True)
+    (work / "gpurun_out" / "rX" / "prof" / "b").mkdir(parents=True)
+    (work / "profiles").mkdir()
+    (work / "gpurun_out" / "rX" / "source.sha256").write_text("0" * 64)
+    for d in ("a", "b"):
+        (work / "gpurun_out" / "rX" / "prof" / d / f"1_kernel_stats.csv").write_text("Name,Calls\n")
+    shutil.copy(os.path.join(ROOT, "tools", "assemble_profiles.py"), work / "assemble_profiles.py")
+    r = subprocess.run([sys.executable, "assemble_profiles.py", "rX", "r99"], cwd=work, capture_output=True, text=True)
+    assert r.returncode != 0 and "more than one run" in (r.stderr + r.stdout)
+    assert not list((work / "profiles").iterdir())
+
+
+def test_source_hash_changes_with_the_sources_only():
+    import hashlib
+
+    from tools.source_hash import source_hash
+
+    h = source_hash()
+    assert len(h) == 64 and h == source_hash()
+    assert h != hashlib.sha256(b"").hexdigest()
