@@ -29,30 +29,42 @@ def _dist():
     return dist
 
 
+class _Gather:
+    """An all-gather of row blocks in flight: ``start`` issues it (asynchronously), ``result`` waits and returns the
+    full (S, C) array.  RCCL over xGMI when the backend is nccl."""
+
+    def __init__(self, local: np.ndarray, S: int, group=None):
+        import torch
+
+        dist = _dist()
+        self.S, self.group = S, group
+        self.world = dist.get_world_size(group)
+        C = local.shape[1]
+        self.maxrows = -(-S // self.world)
+        backend = dist.get_backend(group)
+        dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+        buf = torch.zeros((self.maxrows, C), dtype=torch.float64, device=dev)
+        buf[: local.shape[0]] = torch.from_numpy(np.ascontiguousarray(local)).to(dev)
+        self.out = torch.empty((self.world * self.maxrows, C), dtype=torch.float64, device=dev)
+        self.buf = buf  # kept alive until the collective has completed
+        self.work = dist.all_gather_into_tensor(self.out, buf, group=group, async_op=True)
+
+    def result(self) -> np.ndarray:
+        self.work.wait()
+        out = self.out.cpu().numpy().reshape(self.world, self.maxrows, -1)
+        rows = []
+        for r in range(self.world):
+            lo, hi = shard_bounds(self.S, r, self.world)
+            rows.append(out[r, : hi - lo])
+        return np.concatenate(rows, axis=0)
+
+
 def _all_gather_rows(local: np.ndarray, S: int, group=None) -> np.ndarray:
     """Gather the row blocks of every rank into the full (S, C) array on every rank."""
     dist = _dist()
     if dist is None or dist.get_world_size(group) == 1:
         return local
-    import torch
-
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    C = local.shape[1]
-    maxrows = -(-S // world)
-    backend = dist.get_backend(group)
-    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    buf = torch.zeros((maxrows, C), dtype=torch.float64, device=dev)
-    buf[: local.shape[0]] = torch.from_numpy(np.ascontiguousarray(local)).to(dev)
-    out = torch.empty((world * maxrows, C), dtype=torch.float64, device=dev)
-    dist.all_gather_into_tensor(out, buf, group=group)  # RCCL over xGMI when backend == nccl
-    out = out.cpu().numpy().reshape(world, maxrows, C)
-    rows = []
-    for r in range(world):
-        lo, hi = shard_bounds(S, r, world)
-        rows.append(out[r, : hi - lo])
-    assert rank < world
-    return np.concatenate(rows, axis=0)
+    return _Gather(local, S, group).result()
 
 
 def active_group(group=None):
@@ -94,17 +106,23 @@ def gather_rows(S: int, ncols: int, compute_local, group=None, token: float = 0.
     ``ShardError`` afterwards (a non-positive-definite sample on one shard is an expected event
     during fitting; it must not become a hang).
 
-    The ranks must have been called with the SAME batch.  The status row (exchanged FIRST, fixed shape)
-    carries S, ncols and ``token`` -- the caller's ``fingerprint`` of the full argument arrays: if they
-    differ between ranks (unsynchronised RNG seeds in ``fit``, a speculative batch of another length)
-    every rank raises ``ShardError`` before the data exchange, whose buffer shapes would disagree --
-    instead of silently stitching together rows of different batches."""
+    The ranks must have been called with the SAME batch.  An agreement row (fixed shape, exchanged
+    asynchronously UNDER the local computation) carries S, ncols and ``token`` -- the caller's
+    ``fingerprint`` of the full argument arrays: if they differ between ranks (unsynchronised RNG seeds
+    in ``fit``, a speculative batch of another length) every rank raises ``ShardError`` before the data
+    exchange, whose buffer shapes would disagree -- instead of silently stitching together rows of
+    different batches.  One blocking collective per call: the data exchange, which also carries a status
+    row per rank."""
     rw = active_group(group)
     if rw is None:
         rows, bad = compute_local(0, S)
         return np.asarray(rows, dtype=float).reshape(S, ncols), np.asarray(bad, dtype=bool)
     rank, world = rw
     lo, hi = shard_bounds(S, rank, world)
+    # 1. the agreement exchange -- one fixed-shape row per rank: [S, ncols, fingerprint of the arguments] -- is issued
+    #    BEFORE the local computation and completes under it
+    agreement = _Gather(np.array([[float(S), float(ncols), float(token)]]), world, group)
+    # 2. this rank's block
     local = np.zeros((hi - lo, ncols + 1))
     err = None
     try:
@@ -115,21 +133,29 @@ def gather_rows(S: int, ncols: int, compute_local, group=None, token: float = 0.
     except Exception as e:  # noqa: BLE001 - exchanged, then raised on every rank
         err = e
         local[:] = 0.0
-    # one status row per rank: [S, ncols, fingerprint of the arguments, failed]
-    status = _all_gather_rows(np.array([[float(S), float(ncols), float(token), 0.0 if err is None else 1.0]]),
-                              world, group)
-    if np.any(status[:, :3] != status[0, :3]):
-        detail = ", ".join(f"rank {r}: S={int(status[r, 0])} cols={int(status[r, 1])} crc={int(status[r, 2]):08x}"
+    # 3. every rank sees the same agreement rows and takes the same branch
+    seen = agreement.result()
+    if np.any(seen != seen[0]):
+        detail = ", ".join(f"rank {r}: S={int(seen[r, 0])} cols={int(seen[r, 1])} crc={int(seen[r, 2]):08x}"
                            for r in range(world))
         raise ShardError(
             "the ranks of a sharded evaluation were called with different batches (" + detail + "). Every rank "
             "must pass the same hyperparameter rows: seed NumPy's global RNG identically on all ranks before "
             "GP.fit, or set gp.shard = False to keep this GP rank-local") from err
+    # 4. the data exchange (shapes agree now): the rank's rows plus ONE status row, so that a rank with an empty block
+    #    that failed is heard too.  Blocks are padded to the same height; the status row rides at index maxrows.
+    maxrows = -(-S // world)
+    block = np.zeros((maxrows + 1, ncols + 1))
+    block[: hi - lo] = local
+    block[maxrows, ncols] = 0.0 if err is None else 1.0
+    gathered = _Gather(block, world * (maxrows + 1), group).result().reshape(world, maxrows + 1, ncols + 1)
     if err is not None:
         raise ShardError(f"rank {rank}: {type(err).__name__}: {err}") from err
-    if np.any(status[:, 3] != 0.0):
-        raise ShardError(f"sharded evaluation failed on rank(s) {[r for r in range(world) if status[r, 3] != 0.0]}")
-    full = _all_gather_rows(local, S, group)
+    failed = [r for r in range(world) if gathered[r, maxrows, ncols] != 0.0]
+    if failed:
+        raise ShardError(f"sharded evaluation failed on rank(s) {failed}")
+    full = np.concatenate([gathered[r, : shard_bounds(S, r, world)[1] - shard_bounds(S, r, world)[0]]
+                           for r in range(world)], axis=0)
     return full[:, :ncols].copy(), full[:, ncols] != 0.0
 
 
