@@ -292,8 +292,8 @@ struct gpc_ctx {
   // launch-bound and lose with the extra launches of the blocked solves (N=4096 S=1 2.28 / 2.42 / 2.30 / 2.28;
   // N=2048 S=1 0.96 / 1.01 / 0.98 / 0.98; N=1000 S=8 0.52 / 0.53 / 0.54 / 0.54): below npad = 2048 the round-2 scheme stays.
   int nll_block = -1;
-  // right-looking panels with look-ahead (plan.h: potrf_rl): panel height; 0 = off (the recursion)
   int solves_beside_lauum = 1;  // option: the two triangular mat-vecs of a gradient evaluation run under the W^T W launch
+  // right-looking panels with look-ahead for NLL-only evaluations (plan.h: potrf_rl): panel height; 0 = off (default)
   int rl_panel = 0;
   int rl_ahead_max = 8;  // look-ahead (side stream + reserved CUs) only for batches with S (npad/4096)^3 <= this
   int stable = 0;        // option: every factorization in stable mode (plan.h), not only the jitter retries
