@@ -1,5 +1,7 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): bash tools/gpu_run.sh <tag> [steps]
+# usage (on the GPU box, from the repo root): bash tools/gpu_run.sh <tag> [steps]   -- a FRESH tag per run: the box-side
+# directory is wiped here, but gpurun MERGES the results into the local gpurun_out/<tag>, where an earlier run of the same
+# tag would stay beside them (tools/assemble_profiles.py then refuses the directory)
 # runs: GPU tests -> smoke -> bench -> rocprofv3 kernel trace of the bench; logs under gpurun_out/<tag>/
 set -o pipefail
 TAG=${1:-run}; STEPS=${2:-5}
