@@ -1087,6 +1087,60 @@ class GP:
                 cov[s, :, :] += np.dot(np.eye(N_star), sn2_star) * sn2_mult  # :1659, verbatim semantics
         return mu, cov.transpose(1, 2, 0)
 
+    def random_function(self, X_star, add_noise: bool = False):
+        """One function drawn from the GP at ``X_star`` (reference :2241-2329): a hyperparameter sample is picked
+        with ``np.random``, the values come from that sample's posterior N(f_mu, C) -- the prior when the GP holds
+        no data -- through a factor T of C (T^T T = C, ``_robust_factor``), observation noise on request.  f_mu and
+        C are ``predict_full``'s device products.  ``np.random`` is called as the reference calls it (``randint``
+        for the sample, ``standard_normal`` for the M values, again for the noise), so a seeded draw is the
+        reference's draw; with sharded posteriors every rank calls this with the same seed."""
+        X_star = np.atleast_2d(np.asarray(X_star, dtype=float))
+        s = np.random.randint(0, np.size(self.posteriors))
+        mu, cov = self.predict_full(X_star)
+        f_mu, C = mu[:, [s]], cov[:, :, s]
+        if self.y is None:
+            C = C + np.spacing(1) * np.eye(C.shape[0])  # :2287
+        T = self._robust_factor(C)
+        f_star = np.dot(T.T, np.random.standard_normal((T.shape[0], 1))) + f_mu
+        if not add_noise:
+            return f_star
+        cov_N, noise_N, _ = self._counts()
+        post = self.posteriors[s]
+        sn2 = self.noise.compute(post.hyp[cov_N:cov_N + noise_N], X_star, None, None)
+        mult = getattr(post, "sn2_mult", None)
+        return f_star + np.sqrt(sn2 * (1 if mult is None else mult)) * np.random.standard_normal(size=f_mu.shape)
+
+    @staticmethod
+    def _robust_factor(C):
+        """T with T^T T = C for a covariance matrix that may have lost definiteness to rounding (reference
+        ``__robust_cholesky``, :2331-2355): the upper Cholesky factor when LAPACK finds one; otherwise from the
+        eigen-decomposition of the symmetric part, without the directions whose eigenvalue is within n ulp of the
+        largest -- and a zero matrix (nothing to draw from) when a negative eigenvalue survives that cut."""
+        import scipy.linalg as sla
+
+        try:
+            return sla.cholesky(C, check_finite=False)
+        except sla.LinAlgError:
+            pass
+        w, V = sla.eig((C + C.T) / 2)
+        # the reference's sign step as written (:2338-2340): with r_i the row in which column i is largest, element
+        # (i, j) of the eigenvector matrix changes sign when V[r_i, j] is negative
+        at_max = np.argmax(np.abs(V), axis=0)
+        V = np.where(V[at_max] < 0, -V, V)
+        w = np.real(w)
+        keep = np.abs(w) > np.abs(np.spacing(np.max(w))) * w.shape[0]
+        w = w[keep]
+        if np.any(w < 0):
+            return np.zeros(C.shape)
+        return np.dot(np.diag(np.sqrt(w)), np.real(V[:, keep]).T)
+
+    def __repr__(self):
+        parts = ["D=%d" % self.D] + [
+            "%s=%s" % (k, getattr(self, k).__class__.__name__) for k in ("covariance", "mean", "noise")]
+        n = 0 if self.X is None else self.X.shape[0]
+        s = 0 if self.posteriors is None else np.size(self.posteriors)
+        return "GP(" + ", ".join(parts) + ", N=%d, samples=%d)" % (n, s)
+
     def quad(self, mu, sigma, compute_var: bool = False, separate_samples: bool = False):
         """Bayesian quadrature of the GP against Gaussian measures N(mu_j, diag(sigma_j^2))
         (reference :1818-1981; squared-exponential kernels only).  The kernel-mean vectors z,

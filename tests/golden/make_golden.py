@@ -22,6 +22,9 @@ Files written next to this script:
                    7 and 8 nlZ only); run with the target `fullsize45`
   rank1_cases.npz  GP.update with ONE new point (the reference's rank-one path,
                    gaussian_process.py:750-844), high- and low-noise parametrisation
+  draw_cases.npz   GP.random_function under a fixed global seed (posterior and prior draws, with and without
+                   noise) and the reference's factor of rank-deficient / indefinite covariance matrices
+                   (``__robust_cholesky``); target `draw`
 """
 
 import os
@@ -574,8 +577,69 @@ def rank1_cases():
     np.savez_compressed(os.path.join(HERE, "rank1_cases.npz"), **out)
 
 
+def draw_cases():
+    """GP.random_function (:2241-2329) with np.random seeded before every call, and __robust_cholesky (:2331-2355)
+    on matrices that LAPACK's Cholesky rejects."""
+    out = {}
+    names = []
+    cases = [("se", "const", (1, 0, 0), 33, 2, True), ("matern5", "const", (1, 1, 0), 40, 2, True),
+             ("se", "negquad", (1, 0, 0), 130, 3, True), ("se", "const", (1, 0, 0), 0, 2, False)]
+    for idx, (kname, mname, npar, N, D, data) in enumerate(cases):
+        rng = np.random.default_rng(17000 + idx)
+        cov, mean, noise = KERNELS[kname](), MEANS[mname](), make_noise(npar)
+        gp = gpr.GP(D=D, covariance=cov, mean=mean, noise=noise)
+        cov_N, mean_N, noise_N = cov.hyperparameter_count(D), mean.hyperparameter_count(D), noise.hyperparameter_count()
+        S = 3
+        hyp = np.zeros((S, cov_N + noise_N + mean_N))
+        for s in range(S):
+            h_cov = 0.2 * rng.standard_normal(cov_N)
+            h_cov[:D] += np.log(1.2 * np.sqrt(D))
+            h_noise = [np.log(0.1) + 0.2 * rng.standard_normal()] if npar[0] else []
+            h_mean = {"zero": [], "const": [0.2 * rng.standard_normal()]}.get(
+                mname, [0.2 * rng.standard_normal()] + list(0.5 * rng.standard_normal(D))
+                + list(np.log(4.0) + 0.2 * rng.standard_normal(D)))
+            hyp[s] = np.concatenate([h_cov, h_noise, h_mean])
+        tag = f"d{idx:03d}"
+        names.append(f"{tag}|{kname}|{mname}|{npar[0]}{npar[1]}{npar[2]}|{N}|{D}|{int(data)}")
+        out[tag + "_hyp"] = hyp
+        if data:
+            X = rng.uniform(-3, 3, (N, D))
+            y = np.sin(np.sum(X, 1, keepdims=True) / np.sqrt(D)) + 0.1 * rng.standard_normal((N, 1))
+            s2 = 0.01 + 0.05 * rng.uniform(size=(N, 1)) if npar[1] else None
+            out[tag + "_X"], out[tag + "_y"] = X, y
+            if s2 is not None:
+                out[tag + "_s2"] = s2
+            gp.update(X_new=X, y_new=y, s2_new=s2, hyp=hyp)
+        else:
+            gp.update(hyp=hyp)
+        xs = rng.uniform(-3.5, 3.5, (7, D))
+        out[tag + "_xs"] = xs
+        for k in range(4):  # several seeds: different hyperparameter samples get picked
+            np.random.seed(900 + 10 * idx + k)
+            out[tag + f"_f{k}"] = gp.random_function(xs)
+            np.random.seed(900 + 10 * idx + k)
+            out[tag + f"_y{k}"] = gp.random_function(xs, add_noise=True)
+    # the factor of matrices that are not numerically positive definite
+    rng = np.random.default_rng(17100)
+    A = rng.standard_normal((6, 3))
+    B = rng.standard_normal((5, 5))
+    mats = [A @ A.T,                                   # rank 3 of 6: directions dropped
+            np.ones((4, 4)),                           # rank 1
+            (B + B.T) / 2,                             # indefinite: nothing to draw from
+            np.diag([2.0, 1.0, 0.0, 0.5])]             # an exact zero on the diagonal
+    for k, Cm in enumerate(mats):
+        out[f"rc{k}_C"] = Cm
+        out[f"rc{k}_T"] = gp._GP__robust_cholesky(Cm.copy())
+    out["n_rc"] = np.array(len(mats))
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "draw_cases.npz"), **out)
+    print("draw cases:", len(names), "+", len(mats), "factor cases")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["cov", "core", "prior", "fit", "full", "fullsize", "rank1"]
+    which = sys.argv[1:] or ["cov", "core", "prior", "fit", "full", "fullsize", "rank1", "draw"]
+    if "draw" in which:
+        draw_cases()
     if "fullsize" in which:
         fullsize_cases()
     if "fullsize45" in which:  # not in the default list: ~10 minutes and ~15 GB of host memory

@@ -189,3 +189,25 @@ def test_source_hash_changes_with_the_sources_only():
     h = source_hash()
     assert len(h) == 64 and h == source_hash()
     assert h != hashlib.sha256(b"").hexdigest()
+
+
+def test_factor_of_a_covariance_that_lost_definiteness_matches_the_reference():
+    """GP._robust_factor (the reference's __robust_cholesky, gaussian_process.py:2331-2355) on matrices LAPACK's
+    Cholesky rejects -- rank-deficient, indefinite, an exact zero pivot -- against the reference's own output
+    (tests/golden/draw_cases.npz), and on a positive definite one, where it is the upper Cholesky factor."""
+    import os
+
+    import numpy as np
+    import scipy.linalg as sla
+
+    from gpyreg_amd.gaussian_process import GP
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "draw_cases.npz"), allow_pickle=False)
+    for k in range(int(g["n_rc"])):
+        C, ref = g[f"rc{k}_C"], g[f"rc{k}_T"]
+        T = GP._robust_factor(C.copy())
+        assert T.shape == ref.shape, k
+        assert np.allclose(T, ref, rtol=1e-9, atol=1e-12), k
+    A = np.random.default_rng(5).standard_normal((6, 6))
+    C = A @ A.T + 6 * np.eye(6)
+    assert np.array_equal(GP._robust_factor(C), sla.cholesky(C))
