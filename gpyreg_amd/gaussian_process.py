@@ -917,7 +917,10 @@ class GP:
                 made["handle"].free()
             raise LinAlgError("Singular matrix for L Cholesky decomposition")
         handle = made.get("handle")
-        lo, hi = made.get("lo", 0), made.get("hi", 0)
+        if sharded:  # (a rank with no sample of the set made no handle: its block is empty, at its place in the order)
+            lo, hi = _sh.shard_bounds(S, *_sh.active_group(self.process_group))
+        else:
+            lo, hi = 0, S
         self._post_handle = handle
         self._post_range = (lo, hi, S) if sharded else None
         for i in range(S):
@@ -1065,7 +1068,7 @@ class GP:
                 Kss = np.stack([self.covariance.compute(p.hyp[0:cov_N], x_star) for p in local_posts])
                 fmu, _, fcov = self._post_handle.predict_K(Ks, Kss, want_var=False)
             if self._post_range is not None:
-                both = self._gather_samples(np.concatenate([fmu, fcov.reshape(fcov.shape[0], -1).T], axis=0), x_star)
+                both = self._gather_samples(np.concatenate([fmu, fcov.reshape(fcov.shape[0], N_star * N_star).T], axis=0), x_star)
                 fmu, fcov = both[:N_star], both[N_star:].T.reshape(-1, N_star, N_star)
         for s in range(s_N):
             hyp = self.posteriors[s].hyp

@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, sizes=(1, 5, 16), extras=True):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       GPYREG_AMD_DEVICE="0")
@@ -37,7 +37,7 @@ def _worker(rank, world, port, q):
     out = {}
     try:
         bench.CONFIGS[3] = dict(bench.CONFIGS[3], N=700)
-        for S in (5, 16):
+        for S in sizes:  # S = 1: not sharded (every rank evaluates it); S < world: ranks with NO sample take part
             X, y, hyp = bench.synthetic_problem(3, S)
             xs = X[:40] + 0.05
             ref = bench.make_gp(3, "f64")
@@ -51,7 +51,12 @@ def _worker(rank, world, port, q):
             gp = bench.make_gp(3, "f64")  # shard = True by default
             gp.update(X_new=X, y_new=y, hyp=hyp)
             lo, hi = sharding.shard_bounds(S, rank, world)
-            assert gp._post_range == (lo, hi, S) and gp._post_handle.S == hi - lo
+            if S == 1:
+                assert gp._post_range is None and gp._post_handle.S == 1
+                lo, hi = 0, 1
+            else:
+                assert gp._post_range == (lo, hi, S)
+                assert (gp._post_handle.S == hi - lo) if hi > lo else (gp._post_handle is None or gp._post_handle.S == 0)
             n, d = gp.nll_batch(hyp, compute_grad=True)
             n0, _ = gp.nll_batch(hyp, compute_grad=False)
             mu, s2 = gp.predict(xs, separate_samples=True)
@@ -70,7 +75,8 @@ def _worker(rank, world, port, q):
             )
         # a one-point update of a SHARDED posterior set: every rank appends to its own block in O(N^2) (the handle
         # survives), results equal the unsharded rank-one update bit for bit
-        X, y, hyp = bench.synthetic_problem(3, 5)
+        S1 = 5 if world == 2 else 2  # (with three ranks: rank 2 has nothing to append to and still exchanges)
+        X, y, hyp = bench.synthetic_problem(3, S1)
         xs = X[:40] + 0.05
         ref = bench.make_gp(3, "f64")
         ref.shard = False
@@ -82,11 +88,15 @@ def _worker(rank, world, port, q):
         gp.update(X_new=X[-1:], y_new=y[-1:])
         mu, s2 = gp.predict(xs, separate_samples=True)
         rmu, rs2 = ref.predict(xs, separate_samples=True)
-        lo, hi = sharding.shard_bounds(5, rank, world)
+        lo, hi = sharding.shard_bounds(S1, rank, world)
         out["rank1"] = dict(
-            kept=bool(gp._post_handle is h0 and gp._post_range == (lo, hi, 5) and gp._post_handle.N == X.shape[0]),
+            kept=bool(gp._post_handle is h0 and gp._post_range == (lo, hi, S1)
+                      and (h0 is None or gp._post_handle.N == X.shape[0])),
             pred=bool(np.array_equal(mu, rmu) and np.array_equal(s2, rs2)),
             alpha=bool(all(np.array_equal(gp.posteriors[i].alpha, ref.posteriors[i].alpha) for i in range(lo, hi))))
+        if not extras:
+            q.put((rank, out))
+            return
         # one shard holds a sample that stays non-PD after 10 escalations: EVERY rank raises, nobody hangs
         X, y, hyp = bench.synthetic_problem(3, 4)
         gp = bench.make_gp(3, "f64")
@@ -135,9 +145,33 @@ def test_sharded_gp_equals_unsharded_bitwise_two_ranks_one_gpu():
     for rank in (0, 1):
         r = res[rank]
         assert "exception" not in r, r.get("exception")
-        for S in (5, 16):
+        for S in (1, 5, 16):
             assert all(r[S].values()), (rank, S, sorted(k for k, v in r[S].items() if not v))
         assert all(r["rank1"].values()), (rank, r["rank1"])
         assert r["err"] in ("LinAlgError", "ShardError"), r["err"]
         assert r["mismatch"] is True, r["mismatch"]
         assert r["after"]
+
+
+def test_more_ranks_than_samples_three_ranks_one_gpu():
+    """Two samples over three ranks: rank 2 holds none, factors nothing, and still enters every exchange (agreement row,
+    data exchange with its status row, the sample gathers of predict / predict_full); every rank ends up with the
+    unsharded results bit for bit."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 3, port, q, (2,), False)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    errs = {rank: res[rank]["exception"] for rank in range(3) if "exception" in res[rank]}
+    assert not errs, "\n".join("rank %d: %s" % kv for kv in sorted(errs.items()))
+    for rank in range(3):
+        r = res[rank]
+        assert all(r[2].values()), (rank, sorted(k for k, v in r[2].items() if not v))
+        assert all(r["rank1"].values()), (rank, r["rank1"])

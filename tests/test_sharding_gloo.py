@@ -180,3 +180,55 @@ def test_a_failing_shard_raises_on_every_rank_instead_of_hanging():
         assert res[rank][1] == ([0.0, 1.0, 2.0, 3.0, 4.0], [False, False, False, False, True])
         assert res[rank][2] == [7.0]
         assert res[rank][3:] == [True, True, True]
+
+
+def _many_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    from gpyreg_amd import sharding
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        res = {}
+        for S in (2, 7, 16, 13):  # fewer samples than ranks, uneven blocks, bench.py's 2 per rank, a prime
+            table = np.random.default_rng(S).standard_normal((S, 4))
+            seen = []
+
+            def block(lo, hi, table=table, seen=seen):
+                seen.append((lo, hi))
+                return table[lo:hi], np.arange(lo, hi) % 5 == 1
+
+            rows, bad = sharding.gather_rows(S, 4, block, token=sharding.fingerprint(table))
+            lo, hi = sharding.shard_bounds(S, rank, world)
+            res[S] = (bool(np.array_equal(rows, table)), bool(np.array_equal(bad, np.arange(S) % 5 == 1)),
+                      seen == ([(lo, hi)] if hi > lo else []))
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_ranks_uneven_and_empty_blocks():
+    """The 8-GPU layout on the CPU (gloo): blocks of unequal size, ranks with NO sample (S < world) -- the rows come
+    back complete and in order on every rank, each rank computes its own block once (or nothing)."""
+    import torch.multiprocessing as mp
+
+    from gpyreg_amd import sharding
+
+    world = 8
+    assert [sharding.shard_bounds(2, r, world) for r in range(world)][:3] == [(0, 1), (1, 2), (2, 2)]
+    assert sum(hi - lo for lo, hi in (sharding.shard_bounds(13, r, world) for r in range(world))) == 13
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_many_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank in range(world):
+        for S in (2, 7, 16, 13):
+            assert res[rank][S] == (True, True, True), (rank, S, res[rank][S])
