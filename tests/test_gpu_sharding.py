@@ -175,3 +175,76 @@ def test_more_ranks_than_samples_three_ranks_one_gpu():
         r = res[rank]
         assert all(r[2].values()), (rank, sorted(k for k, v in r[2].items() if not v))
         assert all(r["rank1"].values()), (rank, r["rank1"])
+
+
+def _fit_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      GPYREG_AMD_DEVICE="0")
+    import torch.distributed as dist
+
+    import gpyreg_amd as gpr
+    from gpyreg_amd import sharding
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = {}
+    try:
+        rng = np.random.default_rng(77)
+        N, D = 90, 2
+        X = rng.uniform(-3, 3, (N, D))
+        y = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.standard_normal((N, 1))
+        opts = {"n_samples": 5, "init_N": 96, "thin": 2, "burn": 8, "opts_N": 3}
+        xs = rng.uniform(-3, 3, (12, D))
+
+        def run(shard, seed):
+            gp = gpr.GP(D, gpr.covariance_functions.Matern(5), gpr.mean_functions.ConstantMean(),
+                        gpr.noise_functions.GaussianNoise(constant_add=True))
+            gp.shard = shard
+            gp.set_priors({"covariance_log_lengthscale": None, "covariance_log_outputscale": None, "mean_const": None,
+                           "noise_log_scale": ("gaussian", (np.log(1e-2), 1.0))})
+            np.random.seed(seed)
+            hyp, res, _ = gp.fit(X=X, y=y, options=opts)
+            mu, s2 = gp.predict(xs, add_noise=False)
+            return hyp, res.fun, mu, s2, gp
+
+        h0, f0, m0, v0, _ = run(False, 4321)          # rank-local: the unsharded fit
+        h1, f1, m1, v1, gp = run(True, 4321)           # design, lock-step starts, sampler batches, posteriors sharded
+        out["same"] = bool(np.array_equal(h0, h1) and f0 == f1 and np.array_equal(m0, m1) and np.array_equal(v0, v1))
+        lo, hi = sharding.shard_bounds(5, rank, world)
+        out["sharded"] = bool(gp._post_range == (lo, hi, 5))
+        # unsynchronised seeds: the first sharded batch (the design) differs between the ranks -> ShardError on both
+        try:
+            run(True, 100 + rank)
+            out["unsynced"] = "no exception"
+        except sharding.ShardError as e:
+            out["unsynced"] = "different batches" in str(e)
+        q.put((rank, out))
+    except Exception:  # noqa: BLE001
+        import traceback
+
+        q.put((rank, {"exception": traceback.format_exc()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_fit_equals_the_rank_local_fit_two_ranks_one_gpu():
+    """GP.fit under a process group: the design batch, the lock-step multi-start requests, the sampler's speculative
+    batches and the final posteriors are all sharded over the ranks.  With the SAME NumPy seed on both ranks the run
+    is the rank-local run bit for bit (a row of a sharded batch carries the bits of its own evaluation); with
+    different seeds both ranks get ``ShardError`` at the first exchange instead of a stitched-together design."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fit_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    errs = {rank: res[rank]["exception"] for rank in range(2) if "exception" in res[rank]}
+    assert not errs, "\n".join("rank %d: %s" % kv for kv in sorted(errs.items()))
+    for rank in range(2):
+        assert res[rank] == {"same": True, "sharded": True, "unsynced": True}, (rank, res[rank])
