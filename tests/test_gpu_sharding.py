@@ -23,8 +23,58 @@ def _free_port():
     return p
 
 
+def _more_paths(rank, world, S):
+    """The other sharded entry points against their rank-local results: a caller-defined covariance object (K, dK and
+    the cross covariances come from its compute()), user-provided per-point noise, the log predictive density, and
+    Bayesian quadrature -- with S samples over `world` ranks (a rank may hold none)."""
+    import gpyreg_amd as gpr
+    from test_gpu_user_kernel import PySquaredExponential
+
+    rng = np.random.default_rng(31)
+    N, D = 150, 2
+    X = rng.uniform(-3, 3, (N, D))
+    y = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.standard_normal((N, 1))
+    s2 = 0.01 + 0.05 * rng.uniform(size=(N, 1))
+    xs, ys = rng.uniform(-3, 3, (9, D)), rng.standard_normal((9, 1))
+    res = {}
+
+    def both(make, hyp, s2_new=None):
+        outs = []
+        for shard in (False, True):
+            gp = make()
+            gp.shard = shard
+            gp.update(X_new=X, y_new=y, s2_new=s2_new, hyp=hyp)
+            outs.append((gp, gp.nll_batch(hyp, compute_grad=True)))
+        return outs
+
+    def eq(a, b):
+        return bool(all(np.array_equal(u, v) for u, v in zip(a, b)))
+
+    # (1) a Python SE kernel
+    hyp = np.concatenate([0.3 + 0.1 * rng.standard_normal((S, D)), 0.1 * rng.standard_normal((S, 1)),
+                          np.log(0.1) + 0.1 * rng.standard_normal((S, 1)), 0.1 * rng.standard_normal((S, 1))], axis=1)
+    mk = lambda: gpr.GP(D, PySquaredExponential(), gpr.mean_functions.ConstantMean(),
+                        gpr.noise_functions.GaussianNoise(constant_add=True))
+    (g0, n0), (g1, n1) = both(mk, hyp)
+    res["user_kernel"] = eq(n0, n1) and eq(g0.predict(xs, separate_samples=True), g1.predict(xs, separate_samples=True)) \
+        and eq(g0.predict_full(xs[:5]), g1.predict_full(xs[:5]))
+    # (2) built-in SE with user-provided noise; lpd; quadrature
+    mk = lambda: gpr.GP(D, gpr.covariance_functions.SquaredExponential(), gpr.mean_functions.ConstantMean(),
+                        gpr.noise_functions.GaussianNoise(constant_add=True, user_provided_add=True))
+    (g0, n0), (g1, n1) = both(mk, hyp, s2)
+    s2s = 0.02 * np.ones((9, 1))
+    res["user_noise"] = eq(n0, n1) and eq(g0.predict(xs, ys, s2s, add_noise=True, return_lpd=True),
+                                          g1.predict(xs, ys, s2s, add_noise=True, return_lpd=True))
+    qm, qs = rng.uniform(-1, 1, (4, D)), 0.3 + rng.uniform(size=(4, D))
+    res["quad"] = eq(g0.quad(qm, qs, compute_var=True, separate_samples=True),
+                     g1.quad(qm, qs, compute_var=True, separate_samples=True)) \
+        and eq(g0.quad(qm, qs, compute_var=True), g1.quad(qm, qs, compute_var=True))
+    return res
+
+
 def _worker(rank, world, port, q, sizes=(1, 5, 16), extras=True):
     sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       GPYREG_AMD_DEVICE="0")
     import torch.distributed as dist
@@ -94,6 +144,7 @@ def _worker(rank, world, port, q, sizes=(1, 5, 16), extras=True):
                       and (h0 is None or gp._post_handle.N == X.shape[0])),
             pred=bool(np.array_equal(mu, rmu) and np.array_equal(s2, rs2)),
             alpha=bool(all(np.array_equal(gp.posteriors[i].alpha, ref.posteriors[i].alpha) for i in range(lo, hi))))
+        out["paths"] = _more_paths(rank, world, S1)
         if not extras:
             q.put((rank, out))
             return
@@ -148,6 +199,7 @@ def test_sharded_gp_equals_unsharded_bitwise_two_ranks_one_gpu():
         for S in (1, 5, 16):
             assert all(r[S].values()), (rank, S, sorted(k for k, v in r[S].items() if not v))
         assert all(r["rank1"].values()), (rank, r["rank1"])
+        assert all(r["paths"].values()), (rank, r["paths"])
         assert r["err"] in ("LinAlgError", "ShardError"), r["err"]
         assert r["mismatch"] is True, r["mismatch"]
         assert r["after"]
@@ -175,6 +227,7 @@ def test_more_ranks_than_samples_three_ranks_one_gpu():
         r = res[rank]
         assert all(r[2].values()), (rank, sorted(k for k, v in r[2].items() if not v))
         assert all(r["rank1"].values()), (rank, r["rank1"])
+        assert all(r["paths"].values()), (rank, r["paths"])
 
 
 def _fit_worker(rank, world, port, q):
