@@ -42,15 +42,18 @@ class Posterior:
     assigning to them (as ``GP.clean`` does) detaches them from the device copy.
     """
 
-    def __init__(self, hyp, alpha, sW, L, sn2_mult, Lchol, _handle=None, _index=None):
+    def __init__(self, hyp, alpha, sW, L, sn2_mult, Lchol, _handle=None, _index=None, _owner=None):
         self.hyp = hyp
         self._alpha, self._sW, self._L = alpha, sW, L
         self.sn2_mult = sn2_mult
         self.L_chol = Lchol
         self._handle, self._index = _handle, _index
+        self._owner = _owner  # a copied / unpickled GP whose device posteriors are rebuilt at first use (GP._restore)
         self._have = {"alpha": alpha is not None, "sW": sW is not None, "L": L is not None}
 
     def _fetch(self, what):
+        if not self._have[what] and self._handle is None and self._owner is not None:
+            self._owner._restore()
         if self._have[what] or self._handle is None:
             return
         a, w, Lm = self._handle.fetch(
@@ -94,6 +97,14 @@ class Posterior:
     def _detach(self):
         self._handle = None
 
+    def __getstate__(self):
+        # a record copied or pickled BY ITSELF becomes the reference's plain record: its fields are brought to the host
+        for what in ("alpha", "sW", "L"):
+            self._fetch(what)
+        d = self.__dict__.copy()
+        d["_handle"] = d["_index"] = d["_owner"] = None
+        return d
+
 
 _DTYPES = {"f64": _lib.F64, "fp64": _lib.F64, "float64": _lib.F64,
            "f32": _lib.F32, "fp32": _lib.F32, "float32": _lib.F32}
@@ -115,6 +126,7 @@ class GP:
         self.noise = noise
         self._token = None
         self._post_handle = None
+        self._rebuild = False
         self._X = self._y = self._s2 = None
         self.posteriors = None
         self.no_prior = None  # set_bounds must not touch the priors before set_priors ran
@@ -790,6 +802,8 @@ class GP:
         if hyp is not None:
             hyp = np.atleast_2d(np.asarray(hyp, dtype=float)).copy()
 
+        if X_new is not None and hyp is None:
+            self._restore()  # (a copied GP: the rank-one path below extends RESIDENT posteriors)
         rank_one = (X_new is not None and y_new is not None and compute_posterior
                     and self.X is not None and self.y is not None and X_new.shape[0] == 1
                     and y_new.shape[0] == 1 and s2_new is None and hyp is None
@@ -923,6 +937,7 @@ class GP:
             lo, hi = 0, S
         self._post_handle = handle
         self._post_range = (lo, hi, S) if sharded else None
+        self._rebuild = False
         for i in range(S):
             m = full[i, 0]
             mine = handle is not None and lo <= i < hi
@@ -949,6 +964,7 @@ class GP:
         return full.T.copy()
 
     def _drop_handle(self):
+        self._rebuild = False
         if self._post_handle is not None:
             if self.posteriors is not None:
                 for p in self.posteriors:
@@ -970,6 +986,64 @@ class GP:
                 p.L_chol = None
         self._drop_handle()
 
+    # ------------------------------------------------------------------ copies
+    # The reference's GP is plain Python: its users copy.deepcopy() and pickle it (PyVBMC keeps copies of its GPs and
+    # stores them with its results).  Here the posteriors live in HBM behind a handle that cannot be copied by value,
+    # but they are a deterministic function of (X, y, s2, hyp): everything host-side travels with the copy, the device
+    # posteriors are rebuilt on the copy's device when it first needs them (``_restore``; a set that grew by rank-one
+    # appends is rebuilt by full factorizations, equal to rounding).  Fields already materialised on the host
+    # (``Posterior.alpha/.sW/.L``) travel as they are, so a stored GP can be inspected on a machine without a GPU.
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        live = self._post_handle is not None or self._post_range is not None or d.get("_rebuild", False)
+        d["_post_handle"] = None
+        d["_post_range"] = None
+        d["_token"] = None
+        d["process_group"] = None  # a process group does not travel: the copy uses the default group
+        if self.posteriors is not None:
+            d["posteriors"] = [
+                None if p is None else dict(hyp=p.hyp, sn2_mult=p.sn2_mult, L_chol=p.L_chol,
+                                            alpha=p._alpha if p._have["alpha"] else None,
+                                            sW=p._sW if p._have["sW"] else None, L=p._L if p._have["L"] else None)
+                for p in self.posteriors]
+        d["_rebuild"] = bool(live and self.posteriors is not None)
+        return d
+
+    def __setstate__(self, d):
+        posts = d.pop("posteriors", None)
+        self.__dict__.update(d)
+        self.posteriors = None
+        if posts is not None:
+            self.posteriors = np.empty(len(posts), dtype=object)
+            for i, t in enumerate(posts):
+                if t is not None:
+                    self.posteriors[i] = Posterior(t["hyp"], t["alpha"], t["sW"], t["L"], t["sn2_mult"], t["L_chol"],
+                                                   _owner=self if self._rebuild else None)
+
+    def __deepcopy__(self, memo):
+        import copy
+
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        new.__setstate__(copy.deepcopy(self.__getstate__(), memo))
+        new.process_group = self.process_group  # same process: same group
+        return new
+
+    def _restore(self):
+        """Rebuild the device posteriors of a copied / unpickled GP from its hyperparameter samples.  The Posterior
+        records handed out before keep their identity (and whatever they had materialised)."""
+        if not self.__dict__.get("_rebuild", False):
+            return
+        self._rebuild = False
+        old = self.posteriors
+        self.posteriors = np.empty(old.size, dtype=object)
+        self._compute_posteriors(np.stack([p.hyp for p in old]))
+        for i, p in enumerate(old):
+            q = self.posteriors[i]
+            p._handle, p._index, p._owner = q._handle, q._index, None
+            p.sn2_mult, p.L_chol = q.sn2_mult, q.L_chol
+            self.posteriors[i] = p
+
     # ------------------------------------------------------------------ predict
     def predict(self, x_star, y_star=None, s2_star=None, add_noise: bool = False,
                 separate_samples: bool = False, return_lpd: bool = False):
@@ -985,6 +1059,7 @@ class GP:
         mu = np.zeros((N_star, s_N))
         s2 = np.zeros((N_star, s_N))
         if self.y is not None:
+            self._restore()
             if self._post_handle is None and self._post_range is None:
                 raise ValueError("posteriors have been cleaned; call update() first")
             self._ctx()
@@ -1055,6 +1130,7 @@ class GP:
         mu = np.zeros((N_star, s_N))
         cov = np.zeros((s_N, N_star, N_star))
         if self.y is not None:
+            self._restore()
             if self._post_handle is None and self._post_range is None:
                 raise ValueError("posteriors have been cleaned; call update() first")
             self._ctx()
@@ -1160,6 +1236,7 @@ class GP:
         N_star = mu.shape[0]
         sigma = np.tile(sigma, (1, D)) if np.size(sigma) == 1 else np.atleast_2d(np.asarray(sigma, dtype=float))
         sigma = np.broadcast_to(sigma, mu.shape).astype(float)
+        self._restore()
         if self._post_handle is None and self._post_range is None:
             raise ValueError("posteriors have been cleaned; call update() first")
         self._ctx()

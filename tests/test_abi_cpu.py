@@ -211,3 +211,21 @@ def test_factor_of_a_covariance_that_lost_definiteness_matches_the_reference():
     A = np.random.default_rng(5).standard_normal((6, 6))
     C = A @ A.T + 6 * np.eye(6)
     assert np.array_equal(GP._robust_factor(C), sla.cholesky(C))
+
+
+def test_a_gp_without_device_state_pickles_on_the_cpu():
+    """A stored GP must open on a machine without a GPU: pickling touches no device state."""
+    import copy
+    import pickle
+
+    import numpy as np
+
+    import gpyreg_amd as gpr
+
+    gp = gpr.GP(3, gpr.covariance_functions.Matern(3), gpr.mean_functions.NegativeQuadratic(),
+                gpr.noise_functions.GaussianNoise(constant_add=True))
+    gp.temporary_data["note"] = np.arange(3)
+    for cp in (pickle.loads(pickle.dumps(gp)), copy.deepcopy(gp)):
+        assert repr(cp) == repr(gp) and cp.covariance.degree == 3 and cp.posteriors is None and not cp._rebuild
+        assert np.array_equal(cp.temporary_data["note"], np.arange(3))
+        assert np.array_equal(cp.lower_bounds, gp.lower_bounds, equal_nan=True)
