@@ -1214,11 +1214,25 @@ class GP:
         return np.dot(np.diag(np.sqrt(w)), np.real(V[:, keep]).T)
 
     def __repr__(self):
-        parts = ["D=%d" % self.D] + [
-            "%s=%s" % (k, getattr(self, k).__class__.__name__) for k in ("covariance", "mean", "noise")]
-        n = 0 if self.X is None else self.X.shape[0]
-        s = 0 if self.posteriors is None else np.size(self.posteriors)
-        return "GP(" + ", ".join(parts) + ", N=%d, samples=%d)" % (n, s)
+        """The reference's attribute dump (``self.<name> = <summary>``, :64-81 with ``formatting.full_repr``): the public
+        attributes in its order, small arrays printed with four decimals, large ones by shape; device handles and other
+        private fields are left out."""
+        def short(v):
+            if type(v) is dict:
+                return object.__repr__(v)
+            if not isinstance(v, np.ndarray):
+                return repr(v)
+            if v.dtype != object and v.size < 10:
+                txt = np.array2string(v, precision=4, suppress_small=True, separator=", ")
+                if "\n" in txt:
+                    txt = indent("\n" + txt, "    ")
+                return txt + " : " + type(v).__name__
+            return str(v.shape) + " " + type(v).__name__
+
+        first = ["D", "covariance", "mean", "noise", "X", "y", "s2", "lower_bounds", "upper_bounds", "posteriors"]
+        rest = sorted(k for k in self.__dict__ if not k.startswith("_") and k not in first)
+        lines = ["self.%s = %s" % (k, short(getattr(self, k, None))) for k in first + rest]
+        return "GP:\n" + indent(",\n".join(lines), "    ")
 
     def quad(self, mu, sigma, compute_var: bool = False, separate_samples: bool = False):
         """Bayesian quadrature of the GP against Gaussian measures N(mu_j, diag(sigma_j^2))

@@ -226,6 +226,23 @@ def test_a_gp_without_device_state_pickles_on_the_cpu():
                 gpr.noise_functions.GaussianNoise(constant_add=True))
     gp.temporary_data["note"] = np.arange(3)
     for cp in (pickle.loads(pickle.dumps(gp)), copy.deepcopy(gp)):
-        assert repr(cp) == repr(gp) and cp.covariance.degree == 3 and cp.posteriors is None and not cp._rebuild
+        assert repr(cp).splitlines()[1] == repr(gp).splitlines()[1] == "    self.D = 3," and cp.covariance.degree == 3 and cp.posteriors is None and not cp._rebuild
         assert np.array_equal(cp.temporary_data["note"], np.arange(3))
         assert np.array_equal(cp.lower_bounds, gp.lower_bounds, equal_nan=True)
+
+
+def test_repr_and_str_have_the_reference_layout():
+    """test__str__and__repr__ of the reference (testing/test_gaussian_process.py:1031-1110) looks for these pieces."""
+    import numpy as np
+
+    import gpyreg_amd as gpr
+
+    gp = gpr.GP(1, gpr.covariance_functions.Matern(3), gpr.mean_functions.ConstantMean(),
+                gpr.noise_functions.GaussianNoise(constant_add=True))
+    gp.set_bounds({"covariance_log_lengthscale": (-10.8, 3.0), "covariance_log_outputscale": (-5.0, 5.0),
+                   "noise_log_scale": (-7.0, 2.0), "mean_const": (-3.0, 3.0)})
+    assert "Covariance function: Matern" in str(gp)
+    r = repr(gp)
+    assert r.startswith("GP:\n    self.D = 1,\n    self.covariance = <gpyreg_amd.covariance_functions.Matern object at ")
+    assert "self.lower_bounds = [-10.8" in r and "self.temporary_data = <dict object at " in r
+    assert "_post_handle" not in r and "_token" not in r
