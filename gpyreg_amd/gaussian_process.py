@@ -1320,17 +1320,27 @@ class GP:
         return X, y, s2
 
     def __str__(self):
+        """The reference's summary (:83-139), character for character -- including its line break after a Matern
+        degree and its rule for the commas between the noise flags (only when ``constant_add`` is set)."""
         cov_N, noise_N, mean_N = self._counts()
+        count = lambda n: ", " + str(n) + (" parameter\n" if n == 1 else " parameters\n")
         cov = "Covariance function: " + self.covariance.__class__.__name__
         if self.covariance.__class__.__name__ == "Matern":
-            cov += "(degree=" + str(self.covariance.degree) + ")"
+            cov += "(degree=" + str(self.covariance.degree) + ")\n"
+        noise = "Noise function: " + self.noise.__class__.__name__
+        par = getattr(self.noise, "parameters", None)
+        if par is not None and np.any(par):
+            const, provided, rect = (int(v) for v in par)
+            shown = [t for t, on in (("constant_add=True", const == 1), ("user_provided_add=True", provided == 1),
+                                     ("scale_user_provided=True", provided == 2),
+                                     ("rectified_linear_output_dependent_add=True", rect == 1)) if on]
+            sep = ", " if const == 1 else ""
+            noise += "(" + shown[0] + "".join(sep + t for t in shown[1:]) + ")"
         body = (
             "Dimension: " + str(self.D) + "\n"
-            + cov + ", " + str(cov_N) + (" parameter\n" if cov_N == 1 else " parameters\n")
-            + "Mean function: " + self.mean.__class__.__name__ + ", " + str(mean_N)
-            + (" parameter\n" if mean_N == 1 else " parameters\n")
-            + "Noise function: " + self.noise.__class__.__name__ + ", " + str(noise_N)
-            + (" parameter\n" if noise_N == 1 else " parameters\n")
+            + cov + count(cov_N)
+            + "Mean function: " + self.mean.__class__.__name__ + count(mean_N)
+            + noise + count(noise_N)
             + "Hyperparameter priors: " + ("none\n" if self.no_prior else "present\n")
             + "Hyperparameter samples: "
             + ("0" if self.posteriors is None else str(np.size(self.posteriors)))

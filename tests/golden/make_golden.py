@@ -22,6 +22,9 @@ Files written next to this script:
                    7 and 8 nlZ only); run with the target `fullsize45`
   rank1_cases.npz  GP.update with ONE new point (the reference's rank-one path,
                    gaussian_process.py:750-844), high- and low-noise parametrisation
+  api_sweep_reference.txt  (not written by this script) the output of tools/api_sweep.py run against the reference:
+                   cd /tmp && GPYREG_MODULE=gpyreg PYTHONPATH=/root/reference:/root/repo python3 -W ignore \
+                       /root/repo/tools/api_sweep.py > /root/repo/tests/golden/api_sweep_reference.txt
   draw_cases.npz   GP.random_function under a fixed global seed (posterior and prior draws, with and without
                    noise) and the reference's factor of rank-deficient / indefinite covariance matrices
                    (``__robust_cholesky``); target `draw`
