@@ -25,6 +25,7 @@ Files written next to this script:
   api_sweep_reference.txt  (not written by this script) the output of tools/api_sweep.py run against the reference:
                    cd /tmp && GPYREG_MODULE=gpyreg PYTHONPATH=/root/reference:/root/repo python3 -W ignore \
                        /root/repo/tools/api_sweep.py > /root/repo/tests/golden/api_sweep_reference.txt
+  plugin_sweep_reference.txt  likewise, tools/plugin_sweep.py (host-side plugin protocol; CPU test)
   fit_sweep_reference.txt  likewise, tools/fit_sweep.py (seeded fits over the option edge cases) against the reference
   draw_cases.npz   GP.random_function under a fixed global seed (posterior and prior draws, with and without
                    noise) and the reference's factor of rank-deficient / indefinite covariance matrices

@@ -246,3 +246,42 @@ def test_repr_and_str_have_the_reference_layout():
     assert r.startswith("GP:\n    self.D = 1,\n    self.covariance = <gpyreg_amd.covariance_functions.Matern object at ")
     assert "self.lower_bounds = [-10.8" in r and "self.temporary_data = <dict object at " in r
     assert "_post_handle" not in r and "_token" not in r
+
+
+def test_plugin_protocol_sweep_matches_the_reference_output():
+    """tools/plugin_sweep.py (counts, info, get_bounds_info of every covariance / mean / noise class on four data sets
+    including N = 1 and a duplicated point; values and gradients of every mean and of all 12 noise configurations, with
+    and without user-provided noise) against the reference's output of the same script, to ten digits."""
+    import contextlib
+    import io
+    import os
+    import runpy
+    import warnings
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    buf = io.StringIO()
+    with warnings.catch_warnings(), contextlib.redirect_stdout(buf):
+        warnings.simplefilter("ignore")
+        runpy.run_path(os.path.join(root, "tools", "plugin_sweep.py"), run_name="__main__")
+    mine = buf.getvalue().splitlines()
+    with open(os.path.join(root, "tests", "golden", "plugin_sweep_reference.txt")) as f:
+        ref = [ln.rstrip("\n") for ln in f]
+    assert len(mine) == len(ref) > 700
+
+    def same(a, b):
+        ta, tb = a.split(), b.split()
+        if len(ta) != len(tb):
+            return False
+        for x, y in zip(ta, tb):
+            if x == y:
+                continue
+            try:
+                fx, fy = float(x), float(y)
+            except ValueError:
+                return False
+            if abs(fx - fy) > 1e-9 * max(1.0, abs(fx), abs(fy)):
+                return False
+        return True
+
+    bad = [(r, m) for r, m in zip(ref, mine) if not same(r, m)]
+    assert not bad, "\n".join("reference: %s\nhere:      %s" % p for p in bad[:10])
