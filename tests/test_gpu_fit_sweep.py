@@ -44,6 +44,6 @@ def test_fit_sweep_matches_the_reference_output():
     with open(os.path.join(ROOT, "tests", "golden", "fit_sweep_reference.txt")) as f:
         ref = [ln.rstrip("\n") for ln in f]
     assert len(mine) == len(ref) >= 40, (len(mine), len(ref))
-    assert not any("RAISES" in ln for ln in ref)
+    assert sum("RAISES" in ln for ln in ref) == 2  # the two unknown samplers, by design
     bad = [(r, m) for r, m in zip(ref, mine) if not _close(r, m, 5e-3)]
     assert not bad, "\n".join("reference: %s\nhere:      %s" % p for p in bad[:10])

@@ -83,6 +83,38 @@ def main():
     line("s2fit.pred", *g.predict(xs, s2_star=0.02 * np.ones((5, 1)), add_noise=True))
     rb = g.get_recommended_bounds()
     line("s2fit.recommended", *[np.asarray(rb[n]).ravel() for n in sorted(rb)])
+    # the remaining options on a 2-D problem: random design, caller's widths, bounds passed as options, df_base with
+    # Student-t priors, tolerances, an unknown sampler
+    rng = np.random.default_rng(9)
+    X2 = rng.uniform(-3, 3, (40, 2))
+    y2 = np.sin(X2.sum(1, keepdims=True)) + 0.1 * rng.standard_normal((40, 1))
+    mk2 = lambda: gpr.GP(D=2, covariance=gpr.covariance_functions.Matern(5), mean=gpr.mean_functions.ConstantMean(),
+                         noise=gpr.noise_functions.GaussianNoise(constant_add=True))
+    xs2 = rng.uniform(-3, 3, (4, 2))
+    base = {"n_samples": 3, "thin": 1, "burn": 2, "init_N": 32}
+    variants = [dict(base, init_method="rand"),
+                dict(base, widths=np.array([0.3, 0.3, 0.2, 0.2, 0.5])),
+                dict(base, lower_bounds=np.array([-2.0, -2.0, -3.0, -6.0, -2.0]),
+                     upper_bounds=np.array([3.0, 3.0, 3.0, 1.0, 2.0])),
+                dict(base, df_base=3),
+                dict(base, tol_opt=1e-3, tol_opt_mcmc=1e-2),
+                dict(base, sampler="laplace"),
+                dict(base, sampler="nuts")]
+    for k, opts in enumerate(variants):
+        g = mk2()
+        pri = g.get_priors()
+        pri["noise_log_scale"] = ("student_t", (np.log(1e-2), 1.0, np.nan if k == 3 else 5.0))
+        try:
+            g.set_priors(pri)
+            np.random.seed(600 + k)
+            hyp, res, _ = g.fit(X=X2, y=y2, options=opts)
+            line("more%d.hyp" % k, hyp)
+            line("more%d.res" % k, res.fun, np.asarray(res.x))
+            line("more%d.pred" % k, *g.predict(xs2))
+            line("more%d.bounds" % k, g.lower_bounds, g.upper_bounds)
+            line("more%d.df" % k, g.hyper_priors["df"])
+        except Exception as e:  # noqa: BLE001
+            print("more%d RAISES" % k, type(e).__name__, str(e)[:80])
 
 
 if __name__ == "__main__":
