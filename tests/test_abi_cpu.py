@@ -250,7 +250,7 @@ def test_repr_and_str_have_the_reference_layout():
 
 def test_plugin_protocol_sweep_matches_the_reference_output():
     """tools/plugin_sweep.py (counts, info, get_bounds_info of every covariance / mean / noise class on four data sets
-    including N = 1 and a duplicated point; values and gradients of every mean and of all 12 noise configurations, with
+    including N = 1 and a duplicated point; values and gradients of every mean and of all 16 noise configurations, with
     and without user-provided noise) against the reference's output of the same script, to ten digits."""
     import contextlib
     import io

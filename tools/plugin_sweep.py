@@ -59,8 +59,6 @@ def main():
             print(tag, "value", arr(v), "grad", arr(dv) if np.size(dv) else "[]")
             print(tag, "value only", arr(m.compute(h, X)))
         for c, u, sc, r in itertools.product((False, True), repeat=4):
-            if u and sc:
-                continue
             nf = gpr.noise_functions.GaussianNoise(constant_add=c, user_provided_add=u, scale_user_provided=sc,
                                                    rectified_linear_output_dependent_add=r)
             tag = "noise%d%d%d%d.N%d.D%d" % (c, u, sc, r, N, D)
