@@ -150,6 +150,8 @@ class Context:
         X = _f64(X)
         y = _f64(y).ravel()
         N, D = X.shape
+        if y.size != N:  # (the library reads N values of y: a shorter array would be read past its end)
+            raise ValueError(f"X has {N} points and y has {y.size}: every input needs its observation")
         self._check(self._lib.gpc_set_data(self._h, _ptr(X), _ptr(y), N, D), "gpc_set_data")
         self.N, self.D = N, D
         self.data_token = token
