@@ -130,6 +130,9 @@ class SliceSampler:
             shrink += taken
             k = taken - 1
             if vals[k] > log_u or props[k] == xx[dd]:
+                # the interval as the sequential loop leaves it (the accepted proposal does not shrink it): later
+                # coordinates' step-out evaluations of this sweep read these ends (sample(): x_l, x_r are per sweep)
+                x_l[dd], x_r[dd] = ends[k - 1] if k > 0 else (lo, hi)
                 return props[k], vals[k], raw[k], shrink
             lo, hi = ends[k]
 
@@ -160,7 +163,9 @@ class SliceSampler:
                 rr = np.random.rand()  # position of the current point inside the first interval
                 x_l[dd] = np.fmax(x_l[dd] - rr * self.widths[dd], self.LB_out[dd])
                 x_r[dd] = np.fmin(x_r[dd] + (1 - rr) * self.widths[dd], self.UB_out[dd])
-                if self.step_out:
+                if self.step_out and self.widths[dd] > 0:
+                    # (a width of exactly 0 -- the end-of-burn-in estimate from ONE stored sweep, burn = 2 or 3 -- would
+                    # step out by nothing for ever: the reference's loop, :412-417, does not return there)
                     while self._logp(x_l)[0] > log_u:
                         x_l[dd] -= self.widths[dd]
                     while self._logp(x_r)[0] > log_u:
@@ -193,7 +198,8 @@ class SliceSampler:
                     elif shrink < 2:
                         self.widths[dd] = np.minimum(self.widths[dd] * 1.2, delta)
                 xx[dd] = xprime[dd]
-                x_l[dd] = x_r[dd] = xx[dd]
+                # (x_l, x_r keep this coordinate's final interval until the next sweep, as in the reference, :385-387:
+                # with step_out the later coordinates' interval ends are evaluated THERE, not at the updated point)
             if it >= burn and (it - burn) % thin == 0:
                 k = (it - burn) // thin
                 samples[k] = xx

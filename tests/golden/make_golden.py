@@ -28,6 +28,7 @@ Files written next to this script:
   plugin_sweep_reference.txt  likewise, tools/plugin_sweep.py (host-side plugin protocol; CPU test)
   numerics_sweep_reference.txt  likewise, tools/numerics_sweep.py (189 models through nlZ, predict, lpd, quad, ...)
   update_sweep_reference.txt  likewise, tools/update_sweep.py (GP.update call sequences, a prediction after each)
+  sampler_sweep_reference.txt  likewise, tools/sampler_sweep.py (SliceSampler alone, host only; CPU test)
   fit_sweep_reference.txt  likewise, tools/fit_sweep.py (seeded fits over the option edge cases) against the reference
   draw_cases.npz   GP.random_function under a fixed global seed (posterior and prior draws, with and without
                    noise) and the reference's factor of rank-deficient / indefinite covariance matrices

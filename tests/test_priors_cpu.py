@@ -143,15 +143,18 @@ def test_speculative_slice_sampler_walks_the_sequential_chain():
             raise np.linalg.LinAlgError("a speculative row failed")
         return np.array([logf(x) for x in X])
 
-    out = []
-    for batch in (None, logf_batch):
-        np.random.seed(5)
-        s = SliceSampler(logf, np.zeros(3), None, -4 * np.ones(3), 4 * np.ones(3), {"log_f_batch": batch, "speculate": 4})
-        r = s.sample(120, thin=2, burn=40)
-        out.append((r["samples"], r["f_vals"], s.widths.copy(), np.random.rand(), s.func_count, s.device_calls))
-    (sa, fa, wa, ra, na, da), (sb, fb, wb, rb, nb, db) = out
-    assert np.array_equal(sa, sb) and np.array_equal(fa, fb) and np.array_equal(wa, wb) and ra == rb
-    assert na == nb and db < 0.75 * da
+    for step_out in (False, True):  # (with step_out the interval ends of the coordinates already updated in a sweep
+        out = []                    # are read again: the batched path must leave them where the sequential one does)
+        for batch in (None, logf_batch):
+            calls["n"] = 0
+            np.random.seed(5)
+            s = SliceSampler(logf, np.zeros(3), None, -4 * np.ones(3), 4 * np.ones(3),
+                             {"log_f_batch": batch, "speculate": 4, "step_out": step_out})
+            r = s.sample(120, thin=2, burn=40)
+            out.append((r["samples"], r["f_vals"], s.widths.copy(), np.random.rand(), s.func_count, s.device_calls))
+        (sa, fa, wa, ra, na, da), (sb, fb, wb, rb, nb, db) = out
+        assert np.array_equal(sa, sb) and np.array_equal(fa, fb) and np.array_equal(wa, wb) and ra == rb, step_out
+        assert na == nb and db < (0.9 if step_out else 0.75) * da
 
 
 def test_log_priors_rows_is_bit_identical_to_the_row_loop(g):
@@ -202,3 +205,25 @@ def test_log_priors_rows_is_bit_identical_to_the_row_loop(g):
             assert np.array_equal(lp0[r], lp[r], equal_nan=True)
             compared += 1
     assert compared >= 1000
+
+
+def test_slice_sampler_sweep_matches_the_reference_output():
+    """tools/sampler_sweep.py (a correlated Gaussian, a bounded skewed density; step_out / adaptive / caller's widths /
+    bounds / thinning / burn-in / a second call continuing the chain; the error messages) against the output of the
+    reference's SliceSampler under the same seeds: samples, function values and the state of NumPy's global generator
+    afterwards, to twelve digits."""
+    import contextlib
+    import io
+    import os
+    import runpy
+    import warnings
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    buf = io.StringIO()
+    with warnings.catch_warnings(), contextlib.redirect_stdout(buf):
+        warnings.simplefilter("ignore")
+        runpy.run_path(os.path.join(root, "tools", "sampler_sweep.py"), run_name="__main__")
+    mine = buf.getvalue().splitlines()
+    with open(os.path.join(root, "tests", "golden", "sampler_sweep_reference.txt")) as f:
+        ref = [ln.rstrip("\n") for ln in f]
+    assert len(ref) == 51 and mine == ref, [(r, m) for r, m in zip(ref, mine) if r != m][:3]

@@ -98,6 +98,8 @@ def main():
                      upper_bounds=np.array([3.0, 3.0, 3.0, 1.0, 2.0])),
                 dict(base, df_base=3),
                 dict(base, tol_opt=1e-3, tol_opt_mcmc=1e-2),
+                dict(base, step_out=True),
+                dict(base, adaptive=False, n_samples=4),
                 dict(base, sampler="laplace"),
                 dict(base, sampler="nuts")]
     for k, opts in enumerate(variants):
