@@ -81,7 +81,7 @@ SIGNATURES = {
 DK_PLANE_FN = C.CFUNCTYPE(C.c_int, _vp, C.c_int, C.c_int, _dp)
 
 _lib = None
-_lock = threading.Lock()
+_lock = threading.RLock()
 
 
 def load():
@@ -112,10 +112,24 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(_dp)
 
 
+def _serial(method):
+    """A gpc_ctx is one stream with one workspace: calls on it must not overlap (include/gpcore.h), and ctypes releases
+    the GIL while a call runs.  Every entry of a Context and of its PostHandles takes the context's re-entrant lock."""
+    import functools
+
+    @functools.wraps(method)
+    def locked(self, *a, **k):
+        with (self.lock if isinstance(self, Context) else self.ctx.lock):
+            return method(self, *a, **k)
+
+    return locked
+
+
 class Context:
     """One gpc_ctx (device stream + workspace + resident X, y)."""
 
     def __init__(self, device: int = 0):
+        self.lock = threading.RLock()
         self._lib = load()
         h = _vp()
         rc = self._lib.gpc_create(int(device), C.byref(h))
@@ -146,6 +160,7 @@ class Context:
         return self._lib.gpc_device_info(self._h).decode()
 
     # ---- data -----------------------------------------------------------------
+    @_serial
     def set_data(self, X, y, token=None):
         X = _f64(X)
         y = _f64(y).ravel()
@@ -157,6 +172,7 @@ class Context:
         self.data_token = token
 
     # ---- covariance.compute ---------------------------------------------------
+    @_serial
     def kernel(self, kid, degree, hyp, X, X_star=None, diag=False, grad=False):
         X = _f64(X)
         hyp = _f64(hyp)
@@ -175,6 +191,7 @@ class Context:
         return (K, dK) if grad else K
 
     # ---- core -----------------------------------------------------------------
+    @_serial
     def nll_batch(self, kid, degree, dtype, hyp_cov, m, sn2, sn2_is_vector, want_grad=False,
                   dm=None, dsn2=None):
         """hyp_cov (S,cov_N); m (S,N); sn2 (S,N) if sn2_is_vector else (S,1);
@@ -203,6 +220,7 @@ class Context:
         self._check(rc, "gpc_nll_batch")
         return nlz, dnlz, mult, lchol.astype(bool), info
 
+    @_serial
     def nll_batch_K(self, dtype, K, dK_plane, cov_N, m, sn2, sn2_is_vector, want_grad=False, dm=None,
                     dsn2=None):
         """gpc_nll_batch_K: K (S,N,N) from the caller's covariance object; ``dK_plane(s, p)`` returns
@@ -244,6 +262,7 @@ class Context:
         self._check(rc, "gpc_nll_batch_K")
         return nlz, dnlz, mult, lchol.astype(bool), info
 
+    @_serial
     def posterior_batch_K(self, dtype, K, m, sn2, sn2_is_vector):
         K, m, sn2 = _f64(K), _f64(m), _f64(sn2)
         S = K.shape[0]
@@ -259,6 +278,7 @@ class Context:
         self._check(rc, "gpc_posterior_batch_K")
         return PostHandle(self, h, S, self.N), mult, lchol.astype(bool), info
 
+    @_serial
     def posterior_batch(self, kid, degree, dtype, hyp_cov, m, sn2, sn2_is_vector):
         hyp_cov = _f64(hyp_cov)
         m = _f64(m)
@@ -277,19 +297,23 @@ class Context:
         self._check(rc, "gpc_posterior_batch")
         return PostHandle(self, h, S, self.N), mult, lchol.astype(bool), info
 
+    @_serial
     def last_timing(self):
         a, b = C.c_double(), C.c_double()
         self._lib.gpc_last_timing(self._h, C.byref(a), C.byref(b))
         return a.value, b.value
 
+    @_serial
     def set_option(self, name: str, value: int):
         self._check(self._lib.gpc_set_option(self._h, name.encode(), int(value)), "gpc_set_option")
 
+    @_serial
     def last_lauum_timing(self):
         a, b = C.c_double(), C.c_double()
         self._lib.gpc_last_lauum_timing(self._h, C.byref(a), C.byref(b))
         return a.value, b.value
 
+    @_serial
     def mfma_peak(self, dtype=F64):
         """(TFLOP/s, shader cycles per MFMA per SIMD, clock in GHz) of a bare MFMA loop."""
         t, cyc, ghz = C.c_double(), C.c_double(), C.c_double()
@@ -298,6 +322,7 @@ class Context:
         return t.value, cyc.value, ghz.value
 
     # ---- test hooks -------------------------------------------------------------
+    @_serial
     def debug_gemm(self, A, B, Cm, M, N, K, a_kmajor, b_kmajor, alpha=1.0, beta=0, klo=0, khi=0,
                    lower_only=False, dtype=F64, force_bt=0):
         A, B = _f64(A), _f64(B)
@@ -309,6 +334,7 @@ class Context:
         self._check(rc, "gpc_debug_gemm")
         return Cm
 
+    @_serial
     def debug_factor(self, A, want_inv=True, dtype=F64):
         A = _f64(A)
         n = A.shape[0]
@@ -328,6 +354,7 @@ class PostHandle:
     def __init__(self, ctx: Context, h, S: int, N: int):
         self.ctx, self._h, self.S, self.N = ctx, h, S, N
 
+    @_serial
     def fetch(self, s, alpha=True, sW=True, L=True):
         N = self.N
         a = np.empty(N) if alpha else None
@@ -337,6 +364,7 @@ class PostHandle:
         self.ctx._check(rc, "gpc_post_fetch")
         return a, w, Lm
 
+    @_serial
     def predict(self, x_star):
         xs = _f64(x_star)
         M = xs.shape[0]
@@ -346,6 +374,7 @@ class PostHandle:
         self.ctx._check(rc, "gpc_predict")
         return fmu, fs2
 
+    @_serial
     def predict_K(self, Ks, Kss=None, want_var=True):
         """gpc_predict_K: Ks (S,N,M) caller-provided cross covariances; returns fmu (M,S), the
         variance term fq (M,S; add kss) and, with Kss (S,M,M), the full covariances (S,M,M)."""
@@ -359,6 +388,7 @@ class PostHandle:
         self.ctx._check(rc, "gpc_predict_K")
         return fmu, fq, cov
 
+    @_serial
     def append(self, m_star, sn2_star, y_new):
         """Rank-one append of the point already added to the context's data.  Returns the
         per-sample outcome (bool array): False entries must be recomputed (``recompute``)."""
@@ -370,6 +400,7 @@ class PostHandle:
         self.N += 1
         return ok.astype(bool)
 
+    @_serial
     def append_K(self, Ks, kss, m_star, sn2_star, y_new):
         """``append`` for posteriors built from a caller's covariance object: Ks (S, n) = k_s(X_old, x_new),
         kss (S,) = k_s(x_new, x_new)."""
@@ -384,6 +415,7 @@ class PostHandle:
         self.N += 1
         return ok.astype(bool)
 
+    @_serial
     def recompute(self, idx, hyp_cov, m, sn2, sn2_is_vector, K=None):
         """Full recompute of the listed samples in place (the reference's ``full_updates``).  ``K`` (cnt, N, N):
         the caller's covariance matrices on the extended data (posteriors built from a covariance object)."""
@@ -407,6 +439,7 @@ class PostHandle:
         self.ctx._check(rc, "gpc_post_recompute")
         return mult, lchol.astype(bool), info
 
+    @_serial
     def predict_full(self, x_star):
         xs = _f64(x_star)
         M = xs.shape[0]
@@ -416,6 +449,7 @@ class PostHandle:
         self.ctx._check(rc, "gpc_predict_full")
         return fmu, cov
 
+    @_serial
     def quad(self, mu, sigma, compute_var):
         mu, sigma = _f64(mu), _f64(sigma)
         M = mu.shape[0]
@@ -425,6 +459,7 @@ class PostHandle:
         self.ctx._check(rc, "gpc_quad")
         return za, zkz
 
+    @_serial
     def free(self):
         if self._h:
             self.ctx._lib.gpc_post_free(self._h)
@@ -448,8 +483,9 @@ def default_device() -> int:
 def context(device: int | None = None) -> Context:
     """Process-wide context of a device (created on first use)."""
     dev = default_device() if device is None else int(device)
-    ctx = _contexts.get(dev)
-    if ctx is None or ctx._h is None:
-        ctx = Context(dev)
-        _contexts[dev] = ctx
+    with _lock:
+        ctx = _contexts.get(dev)
+        if ctx is None or ctx._h is None:
+            ctx = Context(dev)
+            _contexts[dev] = ctx
     return ctx

@@ -106,6 +106,19 @@ class Posterior:
         return d
 
 
+def _on_device(method):
+    """The device copy of (X, y) belongs to the context, not to the GP: uploading this GP's data and the call that
+    uses it must not be separated by another thread's GP on the same device.  Held for the whole method (re-entrant)."""
+    import functools
+
+    @functools.wraps(method)
+    def held(self, *a, **k):
+        with _lib.context(self.device).lock:
+            return method(self, *a, **k)
+
+    return held
+
+
 _DTYPES = {"f64": _lib.F64, "fp64": _lib.F64, "float64": _lib.F64,
            "f32": _lib.F32, "fp32": _lib.F32, "float32": _lib.F32}
 
@@ -300,6 +313,7 @@ class GP:
             raise LinAlgError("Singular matrix for L Cholesky decomposition")
         return full[:, 0].copy(), (full[:, 1:].copy() if compute_grad else None)
 
+    @_on_device
     def _nll_batch_local(self, hyp, compute_grad):
         """This rank's evaluation of the rows of ``hyp``: nlZ, dnlZ | None, info (no exception for a
         failed sample: the caller decides, after the exchange when sharded)."""
@@ -855,6 +869,7 @@ class GP:
             for i in range(s_N):
                 self.posteriors[i] = Posterior(hyp[i, :], None, None, None, None, None)
 
+    @_on_device
     def _append_point(self, local_posts, append_args, X_new, y_new):
         """The rank-one path on this rank's posteriors (all of them unless the set is sharded): append on the device,
         recompute alone the ones whose append is unstable (``sqrt_arg <= 0``, :789-798, :866-869), then -- under a
@@ -893,6 +908,7 @@ class GP:
             p._alpha = p._sW = p._L = None  # cached host copies are stale; refetched lazily
             p._have = {"alpha": False, "sW": False, "L": False}
 
+    @_on_device
     def _compute_posteriors(self, hyp):
         """S x ``__core_computation(hyp, 0, 0)`` (reference :876-879) in one batch.  Under a process
         group the samples are block-partitioned: this rank factors and keeps ONLY its block
@@ -1045,6 +1061,7 @@ class GP:
             self.posteriors[i] = p
 
     # ------------------------------------------------------------------ predict
+    @_on_device
     def predict(self, x_star, y_star=None, s2_star=None, add_noise: bool = False,
                 separate_samples: bool = False, return_lpd: bool = False):
         """Posterior mean and variance at ``x_star`` (reference :1663-1816).  The K*
@@ -1120,6 +1137,7 @@ class GP:
             return mu, s2, lpd
         return mu, s2
 
+    @_on_device
     def predict_full(self, x_star, y_star=None, s2_star=None, add_noise: bool = False):
         """Posterior mean and FULL covariance per hyperparameter sample (reference :1561-1661):
         mu (M, S), cov (M, M, S).  K**, Ks, V = L^-T Ks and K** - V^T V are device products."""
@@ -1234,6 +1252,7 @@ class GP:
         lines = ["self.%s = %s" % (k, short(getattr(self, k, None))) for k in first + rest]
         return "GP:\n" + indent(",\n".join(lines), "    ")
 
+    @_on_device
     def quad(self, mu, sigma, compute_var: bool = False, separate_samples: bool = False):
         """Bayesian quadrature of the GP against Gaussian measures N(mu_j, diag(sigma_j^2))
         (reference :1818-1981; squared-exponential kernels only).  The kernel-mean vectors z,
