@@ -133,6 +133,20 @@ def main():
     attempt("shapes.bad", lambda: g3._convert_shapes(np.zeros((3, 2)), np.zeros(3), None))
     attempt("shapes.update_1d", lambda: (g3.update(X_new=x1, y_new=np.sin(x1), s2_new=0.01 * np.ones(9),
                                                    hyp=np.array([[0.1, 0.0, np.log(0.1)]])), g3.predict(np.array([0.3]), s2_star=0.02))[1])
+    # the same data in other clothes: Fortran order, float32 (exactly representable values), integers, a sliced view
+    Xq = np.round(rng.uniform(-3, 3, (18, 2)) * 8) / 8
+    yq = np.round(np.sin(Xq.sum(1, keepdims=True)) * 16) / 16
+    hq = np.array([[0.2, 0.3, 0.1, np.log(0.2), 0.0, 0.1, -0.1, 1.0, 1.2]])
+    big = np.zeros((36, 4))
+    big[::2, 1:3] = Xq
+    for label, Xv, yv in (("plain", Xq, yq), ("fortran", np.asfortranarray(Xq), np.asfortranarray(yq)),
+                          ("float32", Xq.astype(np.float32), yq.astype(np.float32)), ("view", big[::2, 1:3], yq),
+                          ("int_y", Xq, np.round(yq * 0 + 1).astype(int)), ("flat_y", Xq, yq.ravel())):
+        def run(Xv=Xv, yv=yv):
+            g = mk()
+            g.update(X_new=Xv, y_new=yv, hyp=hq)
+            return g.predict(xs, add_noise=True) + (np.array(g.log_likelihood(hq[0])),)
+        attempt("clothes." + label, run)
     attempt("quad.not_se", lambda: g3.quad(0.0, 1.0))
     attempt("str", lambda: str(g3).replace("gpyreg_amd", "gpyreg"))
 
