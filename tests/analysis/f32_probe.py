@@ -1,7 +1,7 @@
 """Where does the fp32 mode lose accuracy?  Device factor / inverse of one N=1408 RQ system in
 fp32 through the debug hooks, decomposed against fp64 LAPACK on the host (GPU box only)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, scipy.linalg as sla
 from oracle import gp_oracle as orc
 from gpyreg_amd import _lib

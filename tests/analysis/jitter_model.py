@@ -13,18 +13,18 @@ suspect, against scipy.linalg.cholesky:
                 every node) with the leaf's arithmetic (= panel_inv inside the leaves)
   device_stable the same in the device's STABLE mode: one refinement step in the leaf's panel solve and at every node
 
-Prints, per fixture sample, the first jitter multiplier 10^k at which each variant succeeds.  usage: python tools/jitter_model.py"""
+Prints, per fixture sample, the first jitter multiplier 10^k at which each variant succeeds.  usage: python tests/analysis/jitter_model.py"""
 import os
 import sys
 
 import numpy as np
 import scipy.linalg as sla
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import parse_core_name  # noqa: E402
-from oracle import gp_oracle as orc  # noqa: E402  (tools/ is analysis, not product)
+from oracle import gp_oracle as orc  # noqa: E402  (under tests/: the oracle is test infrastructure)
 
 
 def system(model, hyp, X, y, s2, mult):

@@ -109,7 +109,7 @@ def potrf_inv(A, W, T, off, n, tile, need_inv, post_mode, log=None, stable=False
 
     ``stable`` (the device's mode for jitter retries, plan.h): the trsm-as-a-product T21 = A21 W11^T is followed by
     one step of refinement against the factor itself, T21 += (A21 - T21 L11^T) W11^T, which makes the panel as
-    accurate as a triangular solve when L11 is ill-conditioned (tools/jitter_model.py); L21 is kept in A at every
+    accurate as a triangular solve when L11 is ill-conditioned (tests/analysis/jitter_model.py); L21 is kept in A at every
     node so that L11 is a complete operand."""
     post_mode = post_mode or stable
     if n == tile:

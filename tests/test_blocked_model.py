@@ -100,7 +100,7 @@ def test_stable_mode_plan_is_the_same_factorization(n, tile):
 
 
 def test_stable_mode_needs_no_more_jitter_than_lapack_on_a_singular_matrix():
-    """The reason stable mode exists (tools/jitter_model.py): near-duplicate inputs, tiny noise.  The fast plan
+    """The reason stable mode exists (tests/analysis/jitter_model.py): near-duplicate inputs, tiny noise.  The fast plan
     (explicit-inverse panel solves) fails at jitter levels where LAPACK succeeds; the stable plan does not."""
     import scipy.linalg as sla
 

@@ -211,7 +211,7 @@ def test_nll_and_grad_match_golden(ctx, core_golden):
     # A failed factorization is retried at the SAME level in stable mode (refined panel solves: the accuracy of a
     # triangular solve) before the jitter goes up, so the device no longer needs systematically more jitter than the
     # reference (round 2: 1-2 decades more on 7 of the 8 singular samples, never less).  What is left is the coin
-    # flip of a numerically indefinite matrix (tools/jitter_model.py: g029 at 10x has a negative fp64 eigenvalue).
+    # flip of a numerically indefinite matrix (tests/analysis/jitter_model.py: g029 at 10x has a negative fp64 eigenvalue).
     assert len(above) <= 3, above
 
 
