@@ -63,7 +63,8 @@ def main():
                                                           scale_user_provided=bool(sc),
                                                           rectified_linear_output_dependent_add=bool(r))
                 k = mk()
-                gp = gpr.GP(D=D, covariance=k, mean=mm(), noise=noise)
+                extra = {"dtype": os.environ["SWEEP_DTYPE"]} if os.environ.get("SWEEP_DTYPE") else {}  # (this package only)
+                gp = gpr.GP(D=D, covariance=k, mean=mm(), noise=noise, **extra)
                 cov_N, noise_N = k.hyperparameter_count(D), noise.hyperparameter_count()
                 mean_N = gp.mean.hyperparameter_count(D)
                 hyp = np.zeros((S, cov_N + noise_N + mean_N))
