@@ -26,7 +26,8 @@ Files written next to this script:
                    cd /tmp && GPYREG_MODULE=gpyreg PYTHONPATH=/root/reference:/root/repo python3 -W ignore \
                        /root/repo/tools/api_sweep.py > /root/repo/tests/golden/api_sweep_reference.txt
   plugin_sweep_reference.txt  likewise, tools/plugin_sweep.py (host-side plugin protocol; CPU test)
-  numerics_sweep_reference.txt  likewise, tools/numerics_sweep.py (189 models through nlZ, predict, lpd, quad, ...)
+  numerics_sweep_reference.txt  likewise, tools/numerics_sweep.py (189 models through nlZ, predict, lpd, quad, ...);
+                   numerics_sweep_n300_reference.txt: the same with SWEEP_N=300
   update_sweep_reference.txt  likewise, tools/update_sweep.py (GP.update call sequences, a prediction after each)
   sampler_sweep_reference.txt  likewise, tools/sampler_sweep.py (SliceSampler alone, host only; CPU test)
   fit_sweep_reference.txt  likewise, tools/fit_sweep.py (seeded fits over the option edge cases) against the reference

@@ -40,13 +40,13 @@ def _line_ok(a, b, tol):
     return True
 
 
-def _run_sweep():
+def _run_sweep(golden="numerics_sweep_reference.txt"):
     buf = io.StringIO()
     with warnings.catch_warnings(), contextlib.redirect_stdout(buf):
         warnings.simplefilter("ignore")
         runpy.run_path(os.path.join(ROOT, "tools", "numerics_sweep.py"), run_name="__main__")
     mine = buf.getvalue().splitlines()
-    with open(os.path.join(ROOT, "tests", "golden", "numerics_sweep_reference.txt")) as f:
+    with open(os.path.join(ROOT, "tests", "golden", golden)) as f:
         ref = [ln.rstrip("\n") for ln in f]
     assert len(mine) == len(ref) > 1900, (len(mine), len(ref))
     return ref, mine
@@ -86,6 +86,23 @@ def test_numerics_sweep_matches_the_reference_output():
     ref, mine = _run_sweep()
     compared, bad = _compare(ref, mine, 1e-7)
     assert compared > 1900
+    assert not bad, "%d lines differ\n" % len(bad) + "\n".join("reference: %s\nhere:      %s" % p for p in bad[:12])
+
+
+def test_numerics_sweep_at_n300_matches_the_reference_output():
+    """The same sweep with N = 300 (the blocked recursion: three levels, odd splits, N_pad = 384) -- and 300 points in
+    a 6 x 6 square make every kernel matrix numerically singular, so the two noise configurations that add (almost)
+    nothing to the diagonal (none at all; a variance of 1e-7) are outside what ANY fp64 factorization pins down: there
+    nlZ is 1.4e7 and the reference and the device agree to 4e-7 only, and the jitter level differs in one model.  They
+    are left out here (the fixture tests check such systems against an extended-precision evaluation instead); the
+    other 135 models agree with the reference to 1e-7 on every line."""
+    os.environ["SWEEP_N"] = "300"
+    try:
+        ref, mine = _run_sweep("numerics_sweep_n300_reference.txt")
+    finally:
+        del os.environ["SWEEP_N"]
+    compared, bad = _compare(ref, mine, 1e-7, skip_noise=("n0000", "n1000lo"))
+    assert compared > 1300, compared
     assert not bad, "%d lines differ\n" % len(bad) + "\n".join("reference: %s\nhere:      %s" % p for p in bad[:12])
 
 

@@ -46,7 +46,7 @@ def main():
     # (constant, user_provided, scale_user_provided, rectified), log noise scale (None: the kernel's default draw)
     noises = [((1, 0, 0, 0), None), ((1, 0, 0, 0), -8.0), ((0, 0, 0, 0), None), ((1, 1, 0, 0), None),
               ((0, 1, 1, 0), None), ((1, 0, 0, 1), None), ((0, 1, 0, 1), None)]
-    N, D, S, M = 24, 2, 2, 5
+    N, D, S, M = int(os.environ.get("SWEEP_N", "24")), 2, 2, 5  # (300: the blocked recursion, three levels, odd splits)
     rng = np.random.default_rng(2024)
     X = rng.uniform(-3, 3, (N, D))
     y = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.standard_normal((N, 1))
