@@ -119,6 +119,23 @@ def _on_device(method):
     return held
 
 
+def _mix_samples(means, variances):
+    """Moments of the equal-weight mixture of per-sample Gaussians, column = sample: (mean (M,1), variance (M,1) |
+    None, between-sample variance).  One sample: returned as it is (between = 0)."""
+    S = means.shape[1]
+    if S == 1:
+        return means, variances, 0
+    centre = np.reshape(np.sum(means, 1), (-1, 1)) / S
+    between = np.sum((means - centre) ** 2, 1) / (S - 1)
+    total = None if variances is None else np.reshape(np.sum(variances, 1) / S + between, (-1, 1))
+    return centre, total, between
+
+
+# GP.fit's options with the reference's defaults (gaussian_process.py:991-1006; "burn": thin * n_samples when unset)
+_FIT_DEFAULTS = {"opts_N": 3, "init_N": 2**10, "init_method": "sobol", "thin": 5, "df_base": 7, "widths": None,
+                 "tol_opt": 1e-5, "tol_opt_mcmc": 1e-3, "sampler": "slicesample", "n_samples": 10, "burn": None,
+                 "lower_bounds": "current", "upper_bounds": "current"}
+
 _DTYPES = {"f64": _lib.F64, "fp64": _lib.F64, "float64": _lib.F64,
            "f32": _lib.F32, "fp32": _lib.F32, "float32": _lib.F32}
 
@@ -528,28 +545,17 @@ class GP:
         batched per iteration (each trajectory is unchanged: it only sees its own values),
         the slice-sampling chain stays sequential, and the final posteriors are one batch.
         """
-        options = options or {}
-        opts_N = options.get("opts_N", 3)
-        init_N = options.get("init_N", 2**10)
-        init_method = options.get("init_method", "sobol")
-        thin = options.get("thin", 5)
-        df_base = options.get("df_base", 7)
-        widths = options.get("widths", None)
-        tol_opt = options.get("tol_opt", 1e-5)
-        tol_opt_mcmc = options.get("tol_opt_mcmc", 1e-3)
-        sampler_name = options.get("sampler", "slicesample")
-        s_N = options.get("n_samples", 10)
-        burn_in = options.get("burn", thin * s_N)
-        lower_bounds = options.get("lower_bounds", "current")
-        upper_bounds = options.get("upper_bounds", "current")
+        o = dict(_FIT_DEFAULTS, **(options or {}))  # the reference's option names and defaults (:991-1006)
+        opts_N, init_N, init_method, thin, s_N = o["opts_N"], o["init_N"], o["init_method"], o["thin"], o["n_samples"]
+        df_base, widths, sampler_name = o["df_base"], o["widths"], o["sampler"]
+        tol_opt, tol_opt_mcmc = o["tol_opt"], o["tol_opt_mcmc"]
+        lower_bounds, upper_bounds = o["lower_bounds"], o["upper_bounds"]
+        burn_in = o["burn"] if "burn" in (options or {}) else thin * s_N
+        options = o
 
-        X, y, s2 = self._convert_shapes(X, y, s2)
-        if X is not None:
-            self.X = X
-        if y is not None:
-            self.y = y
-        if s2 is not None:
-            self.s2 = s2
+        for name, value in zip(("X", "y", "s2"), self._convert_shapes(X, y, s2)):
+            if value is not None:  # data given to fit replace what the GP holds (:1011-1017)
+                setattr(self, name, value)
         cov_N, noise_N, _ = self._counts()
 
         info = [self.covariance.get_bounds_info(self.X, self.y),
@@ -605,12 +611,11 @@ class GP:
             if np.any(idx0):
                 widths_default[idx0] = np.minimum(1, UB[idx0] - LB[idx0])
 
-        eps_LB, eps_UB = np.reshape(LB.copy(), (1, -1)), np.reshape(UB.copy(), (1, -1))
-        LB_idx = (eps_LB != eps_UB) & np.isfinite(eps_LB)
-        UB_idx = (eps_LB != eps_UB) & np.isfinite(eps_UB)
-        eps_LB[LB_idx] = np.nextafter(eps_LB[LB_idx], np.inf)
-        eps_UB[UB_idx] = np.nextafter(eps_UB[UB_idx], -np.inf)
-        hyp = np.minimum(eps_UB, np.maximum(eps_LB, hyp))
+        # starts go strictly inside the box: one ulp off every finite bound of a free coordinate (:1152-1163)
+        free = LB != UB
+        inner_lo = np.where(free & np.isfinite(LB), np.nextafter(LB, np.inf), LB)
+        inner_hi = np.where(free & np.isfinite(UB), np.nextafter(UB, -np.inf), UB)
+        hyp = np.minimum(inner_hi[None, :], np.maximum(inner_lo[None, :], hyp))
 
         # 2. multi-start L-BFGS-B, starts in lock-step (reference :1177-1187)
         nll = np.full((np.maximum(opts_N, 1),), np.inf)
@@ -1121,18 +1126,12 @@ class GP:
         if add_noise:
             s2 = y_s2
         if not separate_samples:
-            if s_N > 1:
-                mu_bar = np.reshape(np.sum(mu, 1), (-1, 1)) / s_N
-                v = np.sum((mu - mu_bar) ** 2, 1) / (s_N - 1)
-                s2 = np.reshape(np.sum(s2, 1) / s_N + v, (-1, 1))
-                mu = mu_bar
-            else:
-                v = 0
-            if return_lpd and add_noise:
-                lpd = -0.5 * (y_star - mu) ** 2 / s2 - 0.5 * np.log(2 * np.pi * s2)
-            elif return_lpd:
-                y_s2 = np.reshape(np.sum(y_s2, 1) / s_N + v, (-1, 1))
-                lpd = -0.5 * (y_star - mu) ** 2 / y_s2 - 0.5 * np.log(2 * np.pi * y_s2)
+            # the mixture over hyperparameter samples (:1789-1811): mean of the means; mean of the variances plus the
+            # spread of the means; the density of y_star under that ONE Gaussian, with the noisy variance
+            mu, s2, between = _mix_samples(mu, s2)
+            if return_lpd:
+                noisy = s2 if add_noise else np.reshape(np.sum(y_s2, 1) / s_N + between, (-1, 1))
+                lpd = -0.5 * (y_star - mu) ** 2 / noisy - 0.5 * np.log(2 * np.pi * noisy)
         if return_lpd:
             return mu, s2, lpd
         return mu, s2
@@ -1299,15 +1298,9 @@ class GP:
                 tau_kk = np.sqrt(2 * sigma**2 + ell**2)
                 nf_kk = np.exp(ln_sf2 + sum_lnell - np.sum(np.log(tau_kk), 1))
                 F_var[:, s] = np.maximum(np.spacing(1), nf_kk - zkz[:, s])
-        if N_s > 1 and not separate_samples:
-            F_bar = np.reshape(np.sum(F, 1), (-1, 1)) / N_s
-            if compute_var:
-                Fss_var = np.sum((F - F_bar) ** 2, 1) / (N_s - 1)
-                F_var = np.reshape(np.sum(F_var, 1) / N_s + Fss_var, (-1, 1))
-            F = F_bar
-        if compute_var:
-            return F, F_var
-        return F
+        if N_s > 1 and not separate_samples:  # (:1968-1976) the same mixture as in predict
+            F, F_var, _ = _mix_samples(F, F_var)
+        return (F, F_var) if compute_var else F
 
     # ------------------------------------------------------------------ misc
     def _convert_shapes(self, X, y, s2):
