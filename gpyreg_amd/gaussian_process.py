@@ -1304,31 +1304,33 @@ class GP:
 
     # ------------------------------------------------------------------ misc
     def _convert_shapes(self, X, y, s2):
-        """Reference :2523-2565."""
-        if X is None and y is None and s2 is None:
+        """Inputs (M, D), observations and per-point noise as columns (M, 1) -- M taken from ``X`` when it is given,
+        from the GP's own data otherwise (reference :2523-2565: same conversions, same exceptions)."""
+        given = [v is not None for v in (X, y, s2)]
+        if not any(given):
             return X, y, s2
-        if X is not None:
-            if X.ndim == 1:
-                X = X[None, :]
+        if given[0]:
+            X = X[None, :] if X.ndim == 1 else X  # one point may come as a flat vector
             if X.ndim != 2:
                 raise AssertionError("X need to be an array of shape (N, D)")
-            N, D = X.shape
-            if D != self.D:
+            if X.shape[1] != self.D:
                 raise AssertionError(
-                    f"The dimension of input data {D}doesn't match GP's input dimension {self.D}.")
+                    f"The dimension of input data {X.shape[1]}doesn't match GP's input dimension {self.D}.")
+            rows = X.shape[0]
+        elif isinstance(self.X, np.ndarray):
+            rows = self.X.shape[0]
         else:
-            try:
-                N, D = self.X.shape
-            except AttributeError:
-                raise AttributeError(f"self.X is not a numpy array, self.X = {self.X}")
-        if y is not None:
-            y = y.reshape(N, 1)
-        if isinstance(s2, (float, int)):
-            s2 = s2 * np.ones((N, 1))
-        elif isinstance(s2, np.ndarray):
-            s2 = s2.reshape(N, 1)
-        elif s2 is not None:
-            raise TypeError("s2 type need to be Union[np.ndarray, float, int, None].")
+            raise AttributeError(f"self.X is not a numpy array, self.X = {self.X}")
+        column = (rows, 1)
+        if given[1]:
+            y = y.reshape(column)
+        if given[2]:
+            if isinstance(s2, np.ndarray):
+                s2 = s2.reshape(column)
+            elif isinstance(s2, (float, int)):
+                s2 = s2 * np.ones(column)  # one noise level for every point
+            else:
+                raise TypeError("s2 type need to be Union[np.ndarray, float, int, None].")
         return X, y, s2
 
     def __str__(self):
