@@ -67,6 +67,7 @@ SIGNATURES = {
     "gpc_last_timing": (C.c_int, [_vp, _dp, _dp]),
     "gpc_last_lauum_timing": (C.c_int, [_vp, _dp, _dp]),
     "gpc_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
+    "gpc_get_option": (C.c_int, [_vp, C.c_char_p, _ip]),
     "gpc_mfma_peak": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
     "gpc_debug_gemm": (
         C.c_int,
@@ -306,6 +307,12 @@ class Context:
     @_serial
     def set_option(self, name: str, value: int):
         self._check(self._lib.gpc_set_option(self._h, name.encode(), int(value)), "gpc_set_option")
+
+    @_serial
+    def get_option(self, name: str) -> int:
+        v = C.c_int()
+        self._check(self._lib.gpc_get_option(self._h, name.encode(), C.byref(v)), "gpc_get_option")
+        return v.value
 
     @_serial
     def last_lauum_timing(self):

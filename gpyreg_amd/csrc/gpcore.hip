@@ -1615,8 +1615,12 @@ int rhs_products(gpc_post* po, int mode, const double* xa, const double* xb, int
   const double* divb = resident ? po->ddv.as<double>() : c->divb.as<double>();
   const double* xsb = resident ? po->dxs.as<double>() : c->xs.as<double>();
 
+  // gpc_last_timing after a predict / predict_full / quad call: device time of the call (first upload to last result
+  // ready) and of its N^2 M products V = W Ks (the launches of gemm.h), summed over the chunks
+  c->ms_total = c->ms_factor = 0;
   for (int s0 = 0; s0 < S; s0 += chunk) {
     const int cnt = std::min(chunk, S - s0);
+    HIPCHK(c, hipEventRecord(c->ev[0], st));
     if (!resident) {
       HIPCHK(c, hipMemcpyAsync(c->spb.p, &po->sp[(size_t)s0 * SP_STRIDE], (size_t)cnt * SP_STRIDE * 8,
                                hipMemcpyHostToDevice, st));
@@ -1663,6 +1667,8 @@ int rhs_products(gpc_post* po, int mode, const double* xa, const double* xb, int
     HIPCHK(c, hipGetLastError());
     // runs of equal L_chol share launches
     int a = 0;
+    HIPCHK(c, hipEventRecord(c->ev[1], st));
+    HIPCHK(c, hipEventRecord(c->ev[2], st));
     while ((want_quad || full) && a < cnt) {
       int e = a;
       while (e < cnt && po->lchol[s0 + e] == po->lchol[s0 + a]) ++e;
@@ -1685,6 +1691,7 @@ int rhs_products(gpc_post* po, int mode, const double* xa, const double* xb, int
       g.A = (lch ? po->W.as<T>() : po->A.as<T>()) + (size_t)(s0 + a) * sM;  // V = W R | G = L R
       g.khi = lch ? KHI_ROW : KHI_FULL;
       HIPCHK(c, launch_gemm<T>(st, g, false, true, len));
+      if (e == cnt) HIPCHK(c, hipEventRecord(c->ev[2], st));  // (several runs: the first launch to the last, with what lies between)
       const T* left = lch ? (const T*)(V + (size_t)a * sKs) : (const T*)(Ks + (size_t)a * sKs);
       hipLaunchKernelGGL((colsum_prod_kernel<T>), dim3(mpad / 64, len), dim3(256), 0, st, left, sKs,
                          (const T*)(V + (size_t)a * sKs), sKs, mpad, npad, mpad, d_v + (size_t)a * mpad);
@@ -1724,7 +1731,15 @@ int rhs_products(gpc_post* po, int mode, const double* xa, const double* xb, int
         if (hfull) memcpy(dst, hfull, (size_t)M * M * 8);
       }
     }
+    HIPCHK(c, hipEventRecord(c->ev[3], st));
     HIPCHK(c, hipStreamSynchronize(st));
+    {
+      float t03 = 0, t12 = 0;
+      (void)hipEventElapsedTime(&t03, c->ev[0], c->ev[3]);
+      (void)hipEventElapsedTime(&t12, c->ev[1], c->ev[2]);
+      c->ms_total += t03;
+      c->ms_factor += t12;
+    }
     for (int i = 0; i < cnt; ++i) {
       const int s = s0 + i;
       for (int j = 0; j < M; ++j) {
@@ -2586,6 +2601,25 @@ int gpc_set_option(gpc_ctx* c, const char* name, int value) {
   else
     FAIL(c, "gpc_set_option: unknown option");
   ++g_alloc_epoch;  // cached launch graphs captured the old launch shapes
+  return 0;
+}
+
+int gpc_get_option(gpc_ctx* c, const char* name, int* value) {
+  if (!c || !name || !value) return -2;
+  const std::string n(name);
+  if (n == "groups") *value = c->groups;
+  else if (n == "small_blocks") *value = gpc::g_small_launch_blocks;
+  else if (n == "dual_launch") *value = gpc::g_dual_launch ? 1 : 0;
+  else if (n == "leaf") *value = gpc::g_leaf_version;
+  else if (n == "defer_min") *value = c->defer_min;
+  else if (n == "defer_reserve") *value = c->defer_reserve;
+  else if (n == "nll_block") *value = c->nll_block;
+  else if (n == "solves_beside_lauum") *value = c->solves_beside_lauum;
+  else if (n == "rl_ahead_max") *value = c->rl_ahead_max;
+  else if (n == "rl_panel") *value = c->rl_panel;
+  else if (n == "stable") *value = c->stable;
+  else if (n == "check_queues") *value = c->check_queues;
+  else FAIL(c, "gpc_get_option: unknown option");
   return 0;
 }
 

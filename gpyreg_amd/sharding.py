@@ -14,6 +14,20 @@ from __future__ import annotations
 import numpy as np
 
 
+# Time this process has spent in the exchange step of sharded calls (bench.py reports it per step): from the end of
+# the rank's own block to the moment the gathered rows are back on the host -- waiting for the slowest rank, the
+# agreement and data all-gathers and their host <-> device copies.
+_stats = {"seconds": 0.0, "calls": 0}
+
+
+def reset_stats():
+    _stats["seconds"], _stats["calls"] = 0.0, 0
+
+
+def stats():
+    return dict(_stats)
+
+
 def shard_bounds(S: int, rank: int, world: int):
     """Rows [lo, hi) of rank ``rank``: contiguous blocks, sizes differ by at most one."""
     base, rem = divmod(S, world)
@@ -134,6 +148,9 @@ def gather_rows(S: int, ncols: int, compute_local, group=None, token: float = 0.
         err = e
         local[:] = 0.0
     # 3. every rank sees the same agreement rows and takes the same branch
+    import time
+
+    t_exchange = time.perf_counter()
     seen = agreement.result()
     if np.any(seen != seen[0]):
         detail = ", ".join(f"rank {r}: S={int(seen[r, 0])} cols={int(seen[r, 1])} crc={int(seen[r, 2]):08x}"
@@ -149,6 +166,8 @@ def gather_rows(S: int, ncols: int, compute_local, group=None, token: float = 0.
     block[: hi - lo] = local
     block[maxrows, ncols] = 0.0 if err is None else 1.0
     gathered = _Gather(block, world * (maxrows + 1), group).result().reshape(world, maxrows + 1, ncols + 1)
+    _stats["seconds"] += time.perf_counter() - t_exchange
+    _stats["calls"] += 1
     if err is not None:
         raise ShardError(f"rank {rank}: {type(err).__name__}: {err}") from err
     failed = [r for r in range(world) if gathered[r, maxrows, ncols] != 0.0]

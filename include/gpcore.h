@@ -178,6 +178,8 @@ int gpc_quad(gpc_post* post, const double* mu, const double* sigma, int M, int c
  * gpc_posterior_batch: whole device section, and the part spent in the MFMA GEMM
  * launches + leaf factorizations (the N^3 work).                                    */
 int gpc_last_timing(gpc_ctx* ctx, double* ms_total, double* ms_factor);
+/* (after gpc_predict / gpc_predict_full / gpc_quad: ms_total = device time of the call, ms_factor = the
+ * duration of its N^2 M product V = W Ks, the GEMM launch of gaussian_process.py:1752-1760)            */
 /* The dominant single kernel of the last gpc_nll_batch with gradient: the W^T W ("lauum")
  * launch of gemm_kernel<T, true, true, ...>.  ms = its duration (hipEvents on the stream it
  * was launched on; the slowest sample group), flops = its algorithmic flops
@@ -192,6 +194,8 @@ int gpc_last_lauum_timing(gpc_ctx* ctx, double* ms, double* flops);
  * (gaussian_process.py:2402), "append_fail_mask" = bit s declares the rank-one append of sample s
  * unstable (:789-798).                                                                            */
 int gpc_set_option(gpc_ctx* ctx, const char* name, int value);
+/* Current value of a tuning switch (so that a caller that changes one for a measurement can put it back). */
+int gpc_get_option(gpc_ctx* ctx, const char* name, int* value);
 /* fp64/fp32 MFMA issue-rate microbenchmark: achieved TFLOP/s of a register-resident
  * v_mfma_{f64,f32}_16x16x4 loop on all CUs (2 waves per SIMD), the shader cycles one
  * SIMD spends per MFMA, and the clock (GHz) the chip held while running it.  Used to

@@ -1,0 +1,94 @@
+"""`bench.py --gpus N` starts its own ranks (no torchrun) and splits the batch as BASELINE.json does.
+
+CPU part: the launcher, the partition and the sharded exchange through `--dry-run` (gloo, no device work).
+GPU part: two self-launched ranks sharing the one GPU of the box run the real timed path."""
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*argv, env=None, timeout=600):
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True,
+                       timeout=timeout, env=e, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_gpus_2_without_a_launcher_starts_two_ranks():
+    r, line = _bench("--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line["n_gpus"] == 2 and line["config"]["process_group_ranks"] == 2
+    assert line["config"]["launcher"] == "self"
+    # BASELINE.json cfg3: 16 samples in all, split over the GPUs -- total work fixed
+    assert line["config"]["global_samples"] == 16 and line["config"]["samples_per_gpu"] == 8
+    assert line["scaling"] == "strong"
+    assert len(r.stdout.strip().splitlines()) == 1  # ONE line on stdout
+
+
+def test_config_split_at_eight_ranks_and_weak_scaling():
+    r, line = _bench("--gpus", "8", "--dry-run", "--steps", "1", "--warmup", "0")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line["n_gpus"] == 8 and line["config"]["global_samples"] == 16 and line["config"]["samples_per_gpu"] == 2
+    r, line = _bench("--gpus", "8", "--dry-run", "--steps", "1", "--warmup", "0", "--config", "5")
+    assert line["config"]["global_samples"] == 64 and line["config"]["samples_per_gpu"] == 8
+    r, line = _bench("--gpus", "4", "--dry-run", "--steps", "1", "--warmup", "0", "--scaling", "weak")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line["n_gpus"] == 4 and line["config"]["global_samples"] == 64 and line["config"]["samples_per_gpu"] == 16
+    assert line["scaling"] == "weak"
+
+
+def test_a_failing_rank_fails_the_launch():
+    r, line = _bench("--gpus", "2", "--dry-run", "--steps", "1", "--warmup", "0", env={"BENCH_TEST_FAIL_RANK": "1"},
+                     timeout=120)
+    assert r.returncode != 0 and line is None
+    assert "rank 1 exited with code 3" in r.stderr
+
+
+def test_under_a_launcher_the_environment_is_used():
+    # what torchrun does: RANK / WORLD_SIZE set from outside, one process per rank
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = {k: v for k, v in os.environ.items()}
+    procs = []
+    for rk in range(2):
+        env = dict(base, RANK=str(rk), LOCAL_RANK=str(rk), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run",
+                                       "--steps", "1", "--warmup", "0"], env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs)
+    line = json.loads([ln for ln in outs[0].splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["launcher"] == "env"
+    assert not [ln for ln in outs[1].splitlines() if ln.startswith("{")]  # only rank 0 reports
+
+
+@pytest.mark.gpu
+def test_two_self_launched_ranks_on_one_gpu_run_the_timed_path():
+    r, line = _bench("--gpus", "2", "--backend", "gloo", "--config", "2", "--samples", "4", "--steps", "2", "--warmup", "1",
+                     "--no-cpu-baseline")
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert line["n_gpus"] == 2 and line["config"]["samples_per_gpu"] == 2 and line["config"]["global_samples"] == 4
+    assert line["value"] > 0 and line["config"]["exchanges_per_step"] == 1.0
+    assert line["config"]["launcher"] == "self" and line["scaling"] == "strong"
+    r1, one = _bench("--gpus", "1", "--config", "2", "--samples", "4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    assert one["n_gpus"] == 1 and abs(one["nlz_sample0"] - line["nlz_sample0"]) == 0.0  # same bits sharded or not
+
+
+@pytest.mark.gpu
+def test_predict_mode_reports_a_roofline_and_matches_the_oracle():
+    r, line = _bench("--mode", "predict", "--config", "2", "--samples", "3", "--points", "300", "--steps", "2", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert line["unit"] == "point-samples/s" and line["value"] > 0
+    assert line["roofline"]["launch_ms"] > 0 and 0 < line["roofline"]["frac"] < 1
+    assert line["cpu_baseline"]["mu_abs_err"] < 1e-8 and line["cpu_baseline"]["s2_rel_err"] < 1e-6
