@@ -226,6 +226,276 @@ __device__ __forceinline__ void lower_tile(int bx, int& ti, int& tj) {
   tj = bx - i * (i + 1) / 2;
 }
 
+// Sum four per-lane values over the 64 lanes of a wave with 7 exchanges instead of 24: two
+// halving steps leave each lane one value (lane bits 5, 4 select which), four more finish it.
+// On return lane l holds the wave total of v[(l >> 4) & 3].  Fixed order: deterministic.
+__device__ __forceinline__ double wave_sum4(double v0, double v1, double v2, double v3, int lane) {
+  const bool b5 = lane & 32, b4 = lane & 16;
+  double k0 = b5 ? v2 : v0, k1 = b5 ? v3 : v1;
+  k0 += __shfl_xor(b5 ? v0 : v2, 32, 64);
+  k1 += __shfl_xor(b5 ? v1 : v3, 32, 64);
+  double u = (b4 ? k1 : k0) + __shfl_xor(b4 ? k0 : k1, 16, 64);
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) u += __shfl_xor(u, o, 64);
+  return u;
+}
+
+
+// ---------------------------------------------------------------------------------
+// fp32 mode (round 4): the same two N^2 passes with a NATIVE fp32 functor.  In fp32 mode the matrix is stored,
+// factored and inverted in fp32 anyway (relative error 6e-8 per entry before the factorization amplifies it), so
+// evaluating exp / log / pow in fp64 VALU (~19 / ~40 instructions each, 4 cycles per wave and instruction) bought no
+// accuracy and made the passes VALU-bound at 6-8 % of HBM peak on cfg4 (N = 16384, D = 20, rational quadratic).
+// Here:  * the scaled inputs are staged in LDS as floats and read two DIMENSIONS at a time (ds_read_b64), the
+//          differences and squares are packed fp32 (v_pk_add_f32 / v_pk_fma_f32: two dimensions per lane and
+//          instruction, the fp32 vector peak), even and odd dimensions summed separately and added at the end --
+//          direct differences, never |x|^2 + |y|^2 - 2 x.y: near-duplicate points keep their relative accuracy;
+//        * exp, log, reciprocal and square root are the hardware's v_exp_f32 / v_log_f32 / v_rcp_f32 / v_sqrt_f32
+//          (~1 ulp, 8 cycles per wave each) instead of fp64 polynomial code;
+//        * per-thread partial sums over the thread's 16 pairs are fp32, everything across lanes, waves and tiles
+//          (wave_sum4, reduce_parts_kernel) stays fp64 and in a fixed order.
+// The reference has no fp32 path; the bar is north_star's 1e-3 on nlZ and gradient.
+// ---------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int XLD32 = DCH + 4;  // LDS row stride in floats: 16 rows x 36 floats hit 16 distinct bank quads (ds_read_b64)
+
+struct PairVal32 {
+  float K, F, Ka;
+};
+
+template <int KIND, int DEG>
+__device__ __forceinline__ PairVal32 pair_eval32(float r2, float sf2, float rqa, float half_over_a) {
+  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+  PairVal32 o;
+  o.Ka = 0.f;
+  if constexpr (KIND == K_SE || KIND == K_SE_ISO) {
+    o.K = sf2 * __builtin_amdgcn_exp2f(r2 * (-0.5f * LOG2E));
+    o.F = o.K;
+  } else if constexpr (KIND == K_MATERN || KIND == K_MATERN_ISO) {
+    const float t = __builtin_amdgcn_sqrtf(r2);
+    const float e = sf2 * __builtin_amdgcn_exp2f(t * -LOG2E);
+    if constexpr (DEG == 1) {
+      o.K = e;
+      o.F = e * __builtin_amdgcn_rcpf(t);  // +inf on the diagonal, as the reference defines it (:276-279)
+    } else if constexpr (DEG == 3) {
+      o.K = fmaf(t, e, e);
+      o.F = e;
+    } else {
+      constexpr float third = 1.0f / 3.0f;
+      o.K = e * fmaf(t, fmaf(t, third, 1.0f), 1.0f);
+      o.F = e * fmaf(t, third, third);
+    }
+  } else {
+    const float Mv = fmaf(r2, half_over_a, 1.0f);
+    const float l2 = __builtin_amdgcn_logf(Mv);  // log2
+    const float rM = __builtin_amdgcn_rcpf(Mv);
+    o.K = sf2 * __builtin_amdgcn_exp2f(-rqa * l2);
+    o.F = o.K * rM;
+    o.Ka = o.K * fmaf(0.5f * r2, rM, -(rqa * LN2) * l2);
+  }
+  return o;
+}
+
+// rows [r0, r0+64), dims [h0, h0+dc) of Xs (double) -> sh[64][XLD32] floats; dims dc .. dc rounded up to even are 0
+__device__ __forceinline__ void stage_x32(float* __restrict__ sh, const double* __restrict__ Xs, int D, int r0, int h0,
+                                          int dc, int t) {
+  const int r = t >> 2;
+  const int dce = (dc + 1) & ~1;
+  for (int h = t & 3; h < dce; h += 4) sh[r * XLD32 + h] = h < dc ? (float)Xs[(size_t)(r0 + r) * D + h0 + h] : 0.f;
+}
+
+// squared distances of the thread's 4 x 4 pairs, two dimensions per packed instruction; leaves the last chunk staged
+__device__ __forceinline__ void tile_r2_32(float (&r2)[4][4], float* __restrict__ xi, float* __restrict__ xj,
+                                           const double* __restrict__ Xs, int D, int i0, int j0, int t, int tx, int ty) {
+  f32x2 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[a][c] = f32x2{0.f, 0.f};
+  for (int h0 = 0; h0 < D; h0 += DCH) {
+    const int dc = min(DCH, D - h0);
+    __syncthreads();
+    stage_x32(xi, Xs, D, i0, h0, dc, t);
+    stage_x32(xj, Xs, D, j0, h0, dc, t);
+    __syncthreads();
+    for (int h = 0; h < dc; h += 2) {
+      f32x2 vi[4], vj[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) vi[a] = *reinterpret_cast<const f32x2*>(xi + (ty + 16 * a) * XLD32 + h);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) vj[c] = *reinterpret_cast<const f32x2*>(xj + (tx + 16 * c) * XLD32 + h);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const f32x2 d = vi[a] - vj[c];
+          acc[a][c] = __builtin_elementwise_fma(d, d, acc[a][c]);
+        }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) r2[a][c] = acc[a][c].x + acc[a][c].y;
+}
+
+template <int KIND, int DEG>
+__device__ __forceinline__ void build_tile32(const CovDesc& cd, const double* __restrict__ Xs_all,
+                                             const double* __restrict__ sp_all, const double* __restrict__ dvec_all,
+                                             int n, int npad, float* __restrict__ A_all, long long sA, int lda,
+                                             int tile, int b, float* __restrict__ xi, float* __restrict__ xj) {
+  const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+  int ti, tj;
+  lower_tile(tile, ti, tj);
+  const int i0 = ti * CT, j0 = tj * CT;
+  const double* Xs = Xs_all + (size_t)b * npad * cd.D;
+  const double* sp = sp_all + (size_t)b * SP_STRIDE;
+  const double* dvec = dvec_all + (size_t)b * npad;
+  float* A = A_all + (size_t)b * sA;
+  float r2[4][4];
+  tile_r2_32(r2, xi, xj, Xs, cd.D, i0, j0, t, tx, ty);
+  const float sfs = (float)(sp[SP_SF2] / sp[SP_KSCALE]);  // K / (sn2_div * sn2_mult), :2416
+  const float rqa = (float)sp[SP_RQA], hoa = (float)(0.5 / sp[SP_RQA]);
+  // straight-line code for the 16 pairs (r2 is finite everywhere, padding included: selects, no branches); the diagonal
+  // -- noise term, identity padding -- exists in diagonal tiles only, a block-uniform branch
+  float v[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int i = i0 + ty + 16 * a, j = j0 + tx + 16 * c;
+      const float k = pair_eval32<KIND, DEG>(r2[a][c], sfs, rqa, hoa).K;
+      v[a][c] = (i < n && j < n) ? k : 0.0f;
+    }
+  if (ti == tj) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int i = i0 + ty + 16 * a, j = j0 + tx + 16 * c;
+        if (i == j) v[a][c] = i < n ? (float)((double)v[a][c] + dvec[i]) : 1.0f;
+      }
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) A[(size_t)(i0 + ty + 16 * a) * lda + j0 + tx + 16 * c] = v[a][c];
+}
+
+template <int KIND, int DEG>
+__device__ __forceinline__ void trace_tile32(const CovDesc& cd, const double* __restrict__ Xs_all,
+                                             const double* __restrict__ sp_all, const double* __restrict__ alpha_all,
+                                             int n, int npad, const float* __restrict__ Kinv_all, long long sK, int ldk,
+                                             double* __restrict__ part_all, int ntiles, double* __restrict__ diagQ_all,
+                                             float* __restrict__ xi, float* __restrict__ xj, double* __restrict__ wpart) {
+  const int t = threadIdx.x, tx = t & 15, ty = t >> 4, b = blockIdx.y;
+  const int lane = t & 63, w = t >> 6;
+  const int P = cd.cov_N + 1;
+  const int P4 = ((P + 3) & ~3) + 4;
+  constexpr bool ISO = (KIND == K_SE_ISO || KIND == K_MATERN_ISO);
+  int ti, tj;
+  lower_tile(blockIdx.x, ti, tj);
+  const int i0 = ti * CT, j0 = tj * CT;
+  const double* Xs = Xs_all + (size_t)b * npad * cd.D;
+  const double* sp = sp_all + (size_t)b * SP_STRIDE;
+  const double* alpha = alpha_all + (size_t)b * npad;
+  const float* Kinv = Kinv_all + (size_t)b * sK;
+  double* part = part_all + ((size_t)b * ntiles + blockIdx.x) * P;
+
+  float kin[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) kin[a][c] = Kinv[(size_t)(i0 + ty + 16 * a) * ldk + j0 + tx + 16 * c];
+  float r2[4][4];
+  tile_r2_32(r2, xi, xj, Xs, cd.D, i0, j0, t, tx, ty);
+  float al_i[4], al_j[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    al_i[a] = (float)alpha[i0 + ty + 16 * a];
+    al_j[a] = (float)alpha[j0 + tx + 16 * a];
+  }
+  const float sf2 = (float)sp[SP_SF2], rqa = (float)sp[SP_RQA], hoa = (float)(0.5 / sp[SP_RQA]);
+  const float invsl = (float)(1.0 / sp[SP_SL]);
+  f32x2 qF[4][4];  // (qF, qF): both dimensions of a packed step are weighted by the pair's factor
+  float g_sf = 0.f, g_a = 0.f, g_iso = 0.f, trq = 0.f;
+  // (one branch per pair, as in the fp64 kernel: evaluating the 16 pairs as straight-line code with selects was
+  // measured -- the compiler then keeps all 16 evaluations in flight, 172 instead of 110 VGPRs, two waves per SIMD
+  // instead of four, 0.61 instead of 0.44 ms on cfg4)
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int i = i0 + ty + 16 * a, j = j0 + tx + 16 * c;
+      const bool valid = (i < n) && (j <= i);
+      float qf = 0.f;
+      if (valid) {
+        const float Q = fmaf(kin[a][c], invsl, -al_i[a] * al_j[c]);
+        const float qw = (i == j) ? Q : 2.0f * Q;
+        const PairVal32 pv = pair_eval32<KIND, DEG>(r2[a][c], sf2, rqa, hoa);
+        g_sf = fmaf(qw, 2.0f * pv.K, g_sf);
+        if constexpr (KIND == K_RQ) g_a = fmaf(qw, pv.Ka, g_a);
+        qf = qw * pv.F;
+        if constexpr (ISO) g_iso = fmaf(qf, r2[a][c], g_iso);
+        if (i == j) {
+          trq += Q;
+          diagQ_all[(size_t)b * npad + i] = (double)Q;
+        }
+      }
+      qF[a][c] = f32x2{qf, qf};  // masked entries exactly 0; a Matern-1 diagonal entry is inf * 0 = NaN, as in the reference
+    }
+
+  const int own = lane >> 4;
+  if constexpr (ISO) {
+    const double u = wave_sum4((double)g_iso, (double)g_sf, (double)trq, 0.0, lane);
+    if ((lane & 15) == 0 && own < 3) wpart[w * P4 + own] = u;
+  } else {
+    // second sweep over the input dimensions, four per reduction: G_h = sum_e qF[e] d_h[e]^2
+    for (int h0 = 0; h0 < cd.D; h0 += DCH) {
+      const int dc = min(DCH, cd.D - h0);
+      if (cd.D > DCH) {
+        __syncthreads();
+        stage_x32(xi, Xs, cd.D, i0, h0, dc, t);
+        stage_x32(xj, Xs, cd.D, j0, h0, dc, t);
+        __syncthreads();
+      }
+      for (int h = 0; h < dc; h += 4) {
+        f32x2 s2[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int hh = h + 2 * q;
+          if (hh >= dc) break;  // block-uniform
+          f32x2 vi[4], vj[4];
+#pragma unroll
+          for (int a = 0; a < 4; ++a) vi[a] = *reinterpret_cast<const f32x2*>(xi + (ty + 16 * a) * XLD32 + hh);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) vj[c] = *reinterpret_cast<const f32x2*>(xj + (tx + 16 * c) * XLD32 + hh);
+          f32x2 s = f32x2{0.f, 0.f};
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const f32x2 d = vi[a] - vj[c];
+              s = __builtin_elementwise_fma(d * d, qF[a][c], s);
+            }
+          s2[q] = s;
+        }
+        const double u = wave_sum4((double)s2[0].x, (double)s2[0].y, (double)s2[1].x, (double)s2[1].y, lane);
+        if ((lane & 15) == 0 && h + own < dc) wpart[w * P4 + h0 + h + own] = u;
+      }
+    }
+    const double u = wave_sum4((double)g_sf, (double)g_a, (double)trq, 0.0, lane);
+    if ((lane & 15) == 0) {
+      if (own == 0) wpart[w * P4 + cd.D] = u;
+      if (own == 1 && KIND == K_RQ) wpart[w * P4 + cd.D + 1] = u;
+      if (own == 2) wpart[w * P4 + P - 1] = u;
+    }
+  }
+  __syncthreads();
+  for (int p = t; p < P; p += 256)
+    part[p] = wpart[p] + wpart[P4 + p] + wpart[2 * P4 + p] + wpart[3 * P4 + p];
+}
+
 // ---------------------------------------------------------------------------------
 // A[b] (lower 64x64 tiles) = K(Xs, Xs) / sp[SP_KSCALE] + diag(dvec), identity in the padding.
 // grid = (lower tiles of npad/64, batch)
@@ -235,6 +505,11 @@ __device__ __forceinline__ void build_tile(const CovDesc& cd, const double* __re
                                            const double* __restrict__ sp_all, const double* __restrict__ dvec_all,
                                            int n, int npad, T* __restrict__ A_all, long long sA, int lda, int tile,
                                            int b, double (*xi)[DCH + 1], double (*xj)[DCH + 1]) {
+  if constexpr (sizeof(T) == 4) {  // fp32 mode: the native fp32 functor (the LDS arrays are reused as float images)
+    build_tile32<KIND, DEG>(cd, Xs_all, sp_all, dvec_all, n, npad, A_all, sA, lda, tile, b,
+                            reinterpret_cast<float*>(&xi[0][0]), reinterpret_cast<float*>(&xj[0][0]));
+    return;
+  }
   const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
   int ti, tj;
   lower_tile(tile, ti, tj);
@@ -306,20 +581,6 @@ __global__ __launch_bounds__(256) void build_persist_kernel(CovDesc cd, const do
   }
 }
 
-// Sum four per-lane values over the 64 lanes of a wave with 7 exchanges instead of 24: two
-// halving steps leave each lane one value (lane bits 5, 4 select which), four more finish it.
-// On return lane l holds the wave total of v[(l >> 4) & 3].  Fixed order: deterministic.
-__device__ __forceinline__ double wave_sum4(double v0, double v1, double v2, double v3, int lane) {
-  const bool b5 = lane & 32, b4 = lane & 16;
-  double k0 = b5 ? v2 : v0, k1 = b5 ? v3 : v1;
-  k0 += __shfl_xor(b5 ? v0 : v2, 32, 64);
-  k1 += __shfl_xor(b5 ? v1 : v3, 32, 64);
-  double u = (b4 ? k1 : k0) + __shfl_xor(b4 ? k0 : k1, 16, 64);
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) u += __shfl_xor(u, o, 64);
-  return u;
-}
-
 // ---------------------------------------------------------------------------------
 // Gradient contraction over the lower triangle of Q = Kinv/sl - alpha alpha^T:
 //   part[b][tile][p], p < P = cov_N + 1:  sum_ij w_ij Q_ij dK_ij/dtheta_p  (w = 2 off-diag)
@@ -341,6 +602,11 @@ __global__ __launch_bounds__(256, GPC_TRACE_WPS) void trace_kernel(CovDesc cd, c
   __shared__ double xi[CT][DCH + 1];
   __shared__ double xj[CT][DCH + 1];
   extern __shared__ double wpart[];  // [4][P4], P4 = P rounded up to a multiple of 4 (+4)
+  if constexpr (sizeof(T) == 4) {
+    trace_tile32<KIND, DEG>(cd, Xs_all, sp_all, alpha_all, n, npad, Kinv_all, sK, ldk, part_all, ntiles, diagQ_all,
+                            reinterpret_cast<float*>(&xi[0][0]), reinterpret_cast<float*>(&xj[0][0]), wpart);
+    return;
+  }
   const int t = threadIdx.x, tx = t & 15, ty = t >> 4, b = blockIdx.y;
   const int lane = t & 63, w = t >> 6;
   const int P = cd.cov_N + 1;

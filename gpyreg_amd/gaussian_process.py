@@ -144,13 +144,21 @@ class GP:
     """A single Gaussian process (reference gaussian_process.py:24-62).
 
     Parameters are the reference's (``D``, ``covariance``, ``mean``, ``noise``) plus
-    two build-only keywords: ``device`` (HIP device index, default LOCAL_RANK or 0)
-    and ``dtype`` ("f64" default, or "f32" for the factorization arithmetic).
+    build-only keywords: ``device`` (HIP device index, default LOCAL_RANK or 0),
+    ``dtype`` ("f64" default, or "f32" for the factorization arithmetic) and
+    ``reference_quirks`` (default False): where the reference's own code is wrong -- three places,
+    all found by diffing against its printed output -- return ITS numbers instead of the corrected ones:
+    the quadrature variance with user-provided noise rescaled by exp(2 hyp[cov_N]) sn2_mult although
+    the factor was scaled by min(sn2) sn2_mult (gaussian_process.py:1921-1922, :1953-1958); quadrature
+    with an isotropic kernel in D > 1 reading the two hyperparameters as ARD length scales
+    (:1898-1903); ``update`` with one new point AND new hyperparameters appending under the old
+    samples and dropping the new ones (:736-746).  Also settable as an attribute afterwards.
     """
 
     def __init__(self, D: int, covariance: object, mean: object, noise: object,
-                 device: int | None = None, dtype: str = "f64"):
+                 device: int | None = None, dtype: str = "f64", reference_quirks: bool = False):
         self.D = D
+        self._quirks = bool(reference_quirks)
         self.covariance = covariance
         self.mean = mean
         self.noise = noise
@@ -182,6 +190,14 @@ class GP:
         self._builtin = getattr(covariance, "_gpc_kernel_id", None) is not None
         self.set_bounds()
         self.set_priors()
+
+    @property
+    def reference_quirks(self):
+        return self.__dict__.get("_quirks", False)
+
+    @reference_quirks.setter
+    def reference_quirks(self, v):
+        self._quirks = bool(v)
 
     # ------------------------------------------------------------------ plumbing
     # X, y and s2 are plain public attributes in the reference and its tests assign them directly
@@ -820,6 +836,12 @@ class GP:
             s2_new = s2_new.copy()
         if hyp is not None:
             hyp = np.atleast_2d(np.asarray(hyp, dtype=float)).copy()
+        if (hyp is not None and self.reference_quirks and X_new is not None and y_new is not None
+                and compute_posterior and self.X is not None and self.y is not None and X_new.shape[0] == 1
+                and y_new.shape[0] == 1 and s2_new is None and self.s2 is None and self.posteriors is not None):
+            # the reference's rank-one test (:738-746) never looks at ``hyp``: the point is appended under the OLD
+            # samples and the new hyperparameters are silently dropped
+            hyp = None
 
         if X_new is not None and hyp is None:
             self._restore()  # (a copied GP: the rank-one path below extends RESIDENT posteriors)
@@ -1028,6 +1050,11 @@ class GP:
                                             sW=p._sW if p._have["sW"] else None, L=p._L if p._have["L"] else None)
                 for p in self.posteriors]
         d["_rebuild"] = bool(live and self.posteriors is not None)
+        # a set that was sharded over a process group is rebuilt collectively (every rank holds a copy and touches it);
+        # anything else is rebuilt on the rank that touches it, with no collective: a stored GP opened by ONE rank of
+        # a group must not wait in an all-gather for peers that never come
+        d["_rebuild_sharded"] = self._post_range is not None or bool(
+            self.__dict__.get("_rebuild") and self.__dict__.get("_rebuild_sharded"))  # (a copy of a copy not yet restored)
         return d
 
     def __setstate__(self, d):
@@ -1058,7 +1085,13 @@ class GP:
         self._rebuild = False
         old = self.posteriors
         self.posteriors = np.empty(old.size, dtype=object)
-        self._compute_posteriors(np.stack([p.hyp for p in old]))
+        shard = self.shard
+        if not self.__dict__.get("_rebuild_sharded", False):
+            self.shard = False
+        try:
+            self._compute_posteriors(np.stack([p.hyp for p in old]))
+        finally:
+            self.shard = shard
         for i, p in enumerate(old):
             q = self.posteriors[i]
             p._handle, p._index, p._owner = q._handle, q._index, None
@@ -1272,21 +1305,51 @@ class GP:
         if self._post_handle is None and self._post_range is None:
             raise ValueError("posteriors have been cleaned; call update() first")
         self._ctx()
-        if self._post_handle is not None:
-            za, zkz = self._post_handle.quad(mu, sigma, compute_var)
-        else:
+        quirks = self.reference_quirks
+        iso = cov_N == 2 and D != 1
+        if quirks:  # the reference evaluates exp(2 hyp[cov_N]) for every sample, variance or not: without a noise
+            for p in self.posteriors:  # hyperparameter that is a mean hyperparameter, or an IndexError (:1921)
+                np.exp(2 * p.hyp[cov_N])
+        if self._post_handle is None:
             za, zkz = np.zeros((N_star, 0)), (np.zeros((N_star, 0)) if compute_var else None)
+        elif quirks and iso:
+            # the reference reads hyp[0:D] as length scales and hyp[D] as the output scale whatever the kernel
+            # (:1898-1903): with an isotropic kernel's two hyperparameters that is [ell, sf, ...] taken for D length
+            # scales.  Its kernel-mean vectors z, built here on the host from that reading, against the device's factors.
+            local, _ = self._local_posteriors()
+            Z = np.empty((len(local), N, N_star))
+            for k, p in enumerate(local):
+                tau = np.sqrt(sigma**2 + np.exp(p.hyp[0:D])**2)
+                lnnf = 2 * p.hyp[D] + np.sum(p.hyp[0:D]) - np.sum(np.log(tau), 1)
+                d2 = np.zeros((N_star, N))
+                for i in range(D):
+                    d2 += ((mu[:, i] - np.reshape(self.X[:, i], (-1, 1))).T / tau[:, i:i + 1]) ** 2
+                Z[k] = np.exp(np.reshape(lnnf, (-1, 1)) - 0.5 * d2).T
+            za, fq, _ = self._post_handle.predict_K(Z, want_var=compute_var)
+            zkz = None if fq is None else -fq  # fq = -z (K + Sigma)^-1 z^T (the variance term of predict)
+        else:
+            za, zkz = self._post_handle.quad(mu, sigma, compute_var)
+        if quirks and compute_var and self._post_handle is not None:
+            # the factor was scaled by sl = min(sn2) sn2_mult, the reference divides by exp(2 hyp[cov_N]) sn2_mult
+            # (:1921-1922, :1953-1958): the same thing only when the noise model is its constant term
+            local, _ = self._local_posteriors()
+            for k, p in enumerate(local):
+                if p.L_chol:
+                    sl = 1.0 / float(np.ravel(p.sW)[0]) ** 2
+                    zkz[:, k] *= sl / (np.exp(2 * p.hyp[cov_N]) * p.sn2_mult)
         if self._post_range is not None:
             both = self._gather_samples(np.concatenate([za, zkz], axis=0) if compute_var else za, mu, sigma)
             za, zkz = both[:N_star], (both[N_star:] if compute_var else None)
         quadratic = isinstance(self.mean, NegativeQuadratic)
         F = np.zeros((N_star, N_s))
         F_var = np.zeros((N_star, N_s)) if compute_var else None
-        iso = cov_N == 2 and D != 1
         for s in range(N_s):
             hyp = self.posteriors[s].hyp
-            ell = np.exp(hyp[0]) * np.ones(D) if iso else np.exp(hyp[0:D])
-            ln_sf2 = 2 * hyp[cov_N - 1]
+            if quirks:  # (:1901-1903 as written)
+                ell, ln_sf2 = np.exp(hyp[0:D]), 2 * hyp[D]
+            else:
+                ell = np.exp(hyp[0]) * np.ones(D) if iso else np.exp(hyp[0:D])
+                ln_sf2 = 2 * hyp[cov_N - 1]
             sum_lnell = np.sum(np.log(ell))
             m0 = 0 if isinstance(self.mean, ZeroMean) else hyp[cov_N + noise_N]
             F[:, s] = za[:, s] + m0

@@ -55,17 +55,19 @@ class GaussianNoise:
             y = np.array([0, 1])
         ylo, yhi = np.min(y), np.max(y)
         tiny = 1e-6
-        # one (LB, UB, PLB, PUB, x0) row per hyperparameter, by block
+        # one (LB, UB, PLB, PUB, x0) row per hyperparameter, by block; a block's rows are only evaluated when the block
+        # is enabled (log(yhi - ylo) and the sample deviation warn on constant or single observations, and the
+        # reference computes them for the constant term only)
         table = {
-            "noise_log_scale": [
+            "noise_log_scale": lambda: [
                 (np.log(tiny), np.log(yhi - ylo), 0.5 * np.log(tiny), np.log(np.std(y, ddof=1)), np.log(1e-3))],
-            "noise_provided_log_multiplier": [
+            "noise_provided_log_multiplier": lambda: [
                 (np.log(1e-3), np.log(1e3), np.log(0.5), np.log(2), np.log(1))],
-            "noise_rectified_log_multiplier": [
+            "noise_rectified_log_multiplier": lambda: [
                 (ylo, yhi, ylo, np.maximum(yhi - 5 * D, ylo), np.maximum(yhi - 10 * D, ylo)),  # threshold
                 (np.log(1e-3), np.log(0.1), np.log(0.01), np.log(0.1), np.log(0.1))],          # log slope
         }
-        rows = [r for name, _ in self._terms() for r in table[name]]
+        rows = [r for name, _ in self._terms() for r in table[name]()]
         cols = np.array(rows, dtype=float).reshape(len(rows), 5)
         out = {k: cols[:, j].copy() for j, k in enumerate(("LB", "UB", "PLB", "PUB", "x0"))}
         open_x0 = np.isnan(out["x0"])

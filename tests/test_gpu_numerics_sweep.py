@@ -89,6 +89,23 @@ def test_numerics_sweep_matches_the_reference_output():
     assert not bad, "%d lines differ\n" % len(bad) + "\n".join("reference: %s\nhere:      %s" % p for p in bad[:12])
 
 
+def test_numerics_sweep_with_reference_quirks_matches_every_line():
+    """``GP(..., reference_quirks=True)``: the quadrature lines the default comparison leaves out or cuts down -- the
+    variance with user-provided noise, the isotropic kernel in D > 1, the IndexError without a constant noise term --
+    are the reference's own numbers (and exception) too: every line of the sweep is compared, nothing filtered."""
+    os.environ["SWEEP_QUIRKS"] = "1"
+    try:
+        ref, mine = _run_sweep()
+    finally:
+        del os.environ["SWEEP_QUIRKS"]
+    bad = [(r, m) for r, m in zip(ref, mine) if r.split()[1] in ("quad", "quad_avg") and not _line_ok(r, m, 1e-7)]
+    nquad = sum(1 for r in ref if r.split()[1] in ("quad", "quad_avg"))
+    assert nquad >= 80, nquad
+    assert not bad, "%d quadrature lines differ\n" % len(bad) + "\n".join("reference: %s\nhere:      %s" % p for p in bad[:12])
+    compared, bad = _compare(ref, mine, 1e-7)  # and nothing else moved
+    assert compared > 1900 and not bad
+
+
 def test_numerics_sweep_at_n300_matches_the_reference_output():
     """The same sweep with N = 300 (the blocked recursion: three levels, odd splits, N_pad = 384) -- and 300 points in
     a 6 x 6 square make every kernel matrix numerically singular, so the two noise configurations that add (almost)

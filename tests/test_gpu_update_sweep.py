@@ -21,7 +21,19 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_update_sequences_match_the_reference_output():
+@pytest.mark.parametrize("quirks", [False, True])
+def test_update_sequences_match_the_reference_output(quirks):
+    """quirks: ``GP(..., reference_quirks=True)`` -- one new point together with new hyperparameters is appended under
+    the OLD samples like the reference does, and that line is compared too."""
+    if quirks:
+        os.environ["SWEEP_QUIRKS"] = "1"
+    try:
+        _check_update_sweep(quirks)
+    finally:
+        os.environ.pop("SWEEP_QUIRKS", None)
+
+
+def _check_update_sweep(quirks):
     buf = io.StringIO()
     with warnings.catch_warnings(), contextlib.redirect_stdout(buf):
         warnings.simplefilter("ignore")
@@ -41,7 +53,7 @@ def test_update_sequences_match_the_reference_output():
             continue
         if broken == name:
             continue
-        if tag == "one_newhyp" and "(6, 3)" in r:
+        if tag == "one_newhyp" and "(6, 3)" in r and not quirks:
             # one new point TOGETHER with new hyperparameters: the reference takes its rank-one path, which never looks
             # at ``hyp`` (gaussian_process.py:738-746 does not test it) -- the new samples are silently dropped.  Here
             # the new hyperparameters are honoured (full recompute): two samples instead of the old three.
@@ -58,4 +70,4 @@ def test_update_sequences_match_the_reference_output():
         if not _line_ok(r, m, 1e-7):
             bad.append((r, m))
     assert not bad, "\n".join("reference: %s\nhere:      %s" % p for p in bad[:10])
-    assert compared == 36, compared  # 12 + 12 + 11 of the three models the reference gets through, 1 of the fourth
+    assert compared == (38 if quirks else 36), compared  # (with quirks: + the one_newhyp lines of the two models that take the rank-one path); 12 + 12 + 11 of the three models the reference gets through, 1 of the fourth

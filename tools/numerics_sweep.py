@@ -64,6 +64,8 @@ def main():
                                                           rectified_linear_output_dependent_add=bool(r))
                 k = mk()
                 extra = {"dtype": os.environ["SWEEP_DTYPE"]} if os.environ.get("SWEEP_DTYPE") else {}  # (this package only)
+                if os.environ.get("SWEEP_QUIRKS"):  # (this package only) the reference's numbers where its code is wrong
+                    extra["reference_quirks"] = True
                 gp = gpr.GP(D=D, covariance=k, mean=mm(), noise=noise, **extra)
                 cov_N, noise_N = k.hyperparameter_count(D), noise.hyperparameter_count()
                 mean_N = gp.mean.hyperparameter_count(D)

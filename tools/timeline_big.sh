@@ -1,6 +1,6 @@
 #!/bin/bash
 # bash tools/timeline_big.sh <tag> <bench args...> [-- ENV=val ...]: per-launch timeline (big launches only) of the LAST timed bench step
-R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=$1; shift; O=$R/gpurun_out/$TAG; rm -rf $O; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=${1:?usage: timeline_big.sh <tag> <bench args...> [-- ENV=val ...]}; shift; O=$R/gpurun_out/$TAG; rm -rf $O; mkdir -p $O
 ARGS=(); while [ $# -gt 0 ] && [ "$1" != "--" ]; do ARGS+=("$1"); shift; done; shift
 for kv in "$@"; do export "$kv"; done
 cd /tmp && export TMPDIR=/tmp

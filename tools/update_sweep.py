@@ -34,8 +34,9 @@ def main():
                ("rect", dict(constant_add=True, rectified_linear_output_dependent_add=True), np.log(0.1))]
     for name, kw, ln in configs:
         noise = gpr.noise_functions.GaussianNoise(**kw)
+        extra = {"reference_quirks": True} if os.environ.get("SWEEP_QUIRKS") else {}  # (this package only)
         gp = gpr.GP(D=D, covariance=gpr.covariance_functions.Matern(5), mean=gpr.mean_functions.ConstantMean(),
-                    noise=noise)
+                    noise=noise, **extra)
         nN = noise.hyperparameter_count()
         S = 3
         hyp = np.zeros((S, 3 + nN + 1))
@@ -82,7 +83,7 @@ def main():
         step("bad_dim", X_new=np.zeros((1, 3)), y_new=np.zeros((1, 1)))
         # a GP that starts without data
         g0 = gpr.GP(D=D, covariance=gpr.covariance_functions.Matern(5), mean=gpr.mean_functions.ConstantMean(),
-                    noise=gpr.noise_functions.GaussianNoise(**kw))
+                    noise=gpr.noise_functions.GaussianNoise(**kw), **extra)
         g0.update(hyp=hyp)
         gp = g0
         show("nodata")
