@@ -188,9 +188,9 @@ __device__ __forceinline__ PairVal pair_eval_t(double r2, double sf2, double rqa
 
 // squared distances of the 4 x 4 pairs of one thread (rows ty + 16a of tile i, rows tx + 16c of tile j),
 // dimensions summed in ascending order; leaves the LAST staged chunk of dimensions in xi / xj
-__device__ __forceinline__ void tile_r2(double (&r2)[4][4], double (*xi)[DCH + 1], double (*xj)[DCH + 1],
-                                        const double* __restrict__ Xs, int D, int i0, int j0, int t, int tx,
-                                        int ty) {
+__device__ __forceinline__ void tile_r2_ab(double (&r2)[4][4], double (*xi)[DCH + 1], double (*xj)[DCH + 1],
+                                           const double* __restrict__ Xa, const double* __restrict__ Xb, int D, int i0,
+                                           int j0, int t, int tx, int ty) {
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -198,8 +198,8 @@ __device__ __forceinline__ void tile_r2(double (&r2)[4][4], double (*xi)[DCH + 1
   for (int h0 = 0; h0 < D; h0 += DCH) {
     const int dc = min(DCH, D - h0);
     __syncthreads();
-    stage_x(xi, Xs, D, i0, h0, dc, t);
-    stage_x(xj, Xs, D, j0, h0, dc, t);
+    stage_x(xi, Xa, D, i0, h0, dc, t);
+    stage_x(xj, Xb, D, j0, h0, dc, t);
     __syncthreads();
     for (int h = 0; h < dc; ++h) {
       double vi[4], vj[4];
@@ -216,6 +216,12 @@ __device__ __forceinline__ void tile_r2(double (&r2)[4][4], double (*xi)[DCH + 1
         }
     }
   }
+}
+
+__device__ __forceinline__ void tile_r2(double (&r2)[4][4], double (*xi)[DCH + 1], double (*xj)[DCH + 1],
+                                        const double* __restrict__ Xs, int D, int i0, int j0, int t, int tx,
+                                        int ty) {
+  tile_r2_ab(r2, xi, xj, Xs, Xs, D, i0, j0, t, tx, ty);
 }
 
 __device__ __forceinline__ void lower_tile(int bx, int& ti, int& tj) {
@@ -750,6 +756,74 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(const double* __restr
   for (int i = threadIdx.x; i < ntiles; i += 256) s += part[((size_t)b * ntiles + i) * P + p];
   s = block_sum_256(s, sh4);
   if (threadIdx.x == 0) out[(size_t)b * P + p] = s;
+}
+
+// ---------------------------------------------------------------------------------
+// predict (round 4): cross covariance Ks[b] (npad x mpad, zero padding) = K(Xs, Xss) in 64 x 64 tiles -- inputs staged
+// in LDS, the pair functor of the kernel build (the same K values as the training matrix, to the bit, where a query
+// point is a training point) -- with the mean product fused in: mupart[b][ti][j] = sum over the 64 rows of tile row ti
+// of Ks[i][j] alpha[i], summed over the tile rows afterwards (colpart_reduce_kernel), so mu = Ks^T alpha
+// (gaussian_process.py:1747) never re-reads Ks.  grid = (mpad/64, npad/64, batch)
+// ---------------------------------------------------------------------------------
+template <typename T, int KIND, int DEG>
+__global__ __launch_bounds__(256) void cross_tile_kernel(CovDesc cd, const double* __restrict__ Xs_all,
+                                                         const double* __restrict__ Xss_all,
+                                                         const double* __restrict__ sp_all,
+                                                         const double* __restrict__ alpha_all, int astride, int n,
+                                                         int npad, int m, int mpad, T* __restrict__ Ks_all, long long sKs,
+                                                         double* __restrict__ mupart_all) {
+  __shared__ double xi[CT][DCH + 1];
+  __shared__ double xj[CT][DCH + 1];
+  __shared__ double red[4][CT];
+  const int t = threadIdx.x, tx = t & 15, ty = t >> 4, b = blockIdx.z;
+  const int lane = t & 63, w = t >> 6;
+  const int i0 = blockIdx.y * CT, j0 = blockIdx.x * CT;
+  const double* Xs = Xs_all + (size_t)b * npad * cd.D;
+  const double* Xss = Xss_all + (size_t)b * mpad * cd.D;
+  const double* sp = sp_all + (size_t)b * SP_STRIDE;
+  const double* alpha = alpha_all + (size_t)b * astride;
+  T* Ks = Ks_all + (size_t)b * sKs;
+  double r2[4][4];
+  tile_r2_ab(r2, xi, xj, Xs, Xss, cd.D, i0, j0, t, tx, ty);
+  const double sf2 = sp[SP_SF2], rqa = sp[SP_RQA];
+  ExpC ex;
+  ex.load();
+  double al[4], s[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int a = 0; a < 4; ++a) al[a] = (i0 + ty + 16 * a) < n ? alpha[i0 + ty + 16 * a] : 0.0;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int i = i0 + ty + 16 * a, j = j0 + tx + 16 * c;
+      double v = 0.0;
+      if (i < n && j < m) v = pair_eval_t<KIND, DEG>(r2[a][c], sf2, rqa, ex).K;
+      const T vt = (T)v;
+      Ks[(size_t)i * mpad + j] = vt;
+      s[c] = fma((double)vt, al[a], s[c]);  // the stored value, so that mu is the product with what the solves read
+    }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    s[c] += __shfl_xor(s[c], 16, 64);
+    s[c] += __shfl_xor(s[c], 32, 64);
+  }
+  if ((lane >> 4) == 0) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[w][tx + 16 * c] = s[c];
+  }
+  __syncthreads();
+  if (t < CT)
+    mupart_all[((size_t)b * (npad / CT) + blockIdx.y) * mpad + j0 + t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+}
+
+// out[b][j] = sum_t part[b][t][j], t ascending.  grid = (mpad/256, batch)
+__global__ __launch_bounds__(256) void colpart_reduce_kernel(const double* __restrict__ part, int nt, int mpad,
+                                                             double* __restrict__ out) {
+  const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= mpad) return;
+  double s = 0.0;
+  for (int k = 0; k < nt; ++k) s += part[((size_t)b * nt + k) * mpad + j];
+  out[(size_t)b * mpad + j] = s;
 }
 
 // ---------------------------------------------------------------------------------

@@ -69,6 +69,10 @@ struct GemmArgs {
   const unsigned short* rsv = nullptr;  // persistent launches: table of the CUs this launch stays off (cu_reserve below)
   int* ctr = nullptr;  // persistent launches: zeroed device counters the blocks draw tiles from
   int ntiles = 0, batch = 0;
+  // EPI = 1 launches (predict): C is not stored; colsq[(b * tiles_m + ti) * N + col] receives the sum over the 128 rows
+  // of tile row ti of (alpha * C[row][col])^2 -- the column sums of squares of V = W Ks (gaussian_process.py:1756-1760)
+  // per tile row, in a fixed order; a small reduction over the tile rows follows
+  double* colsq = nullptr;
 };
 inline int g_gemm_flags = 8 | 16;  // bit 3: XCD-affine tile queues in persistent launches; bit 4: XCD-aware order of plain launches
 
@@ -182,7 +186,7 @@ __device__ __forceinline__ void tri_tile(int tile, int& ti, int& tj) {
 // HO ("hand-off", experiments only: tools/seam_probe.hip): operands are loaded with sc1 (L1-bypassing) loads and the
 // result is stored with agent-scope (write-through, sc1) stores, the forms MI355X_MICROARCH.md prescribes for bytes
 // that cross workgroups INSIDE one launch.
-template <typename T, bool AKM, bool BKM, int BT, int NW, int HO = 0>
+template <typename T, bool AKM, bool BKM, int BT, int NW, int HO = 0, int EPI = 0>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const int by, T* __restrict__ smem) {
   using acc_t = typename MM<T>::acc_t;
   using vec_t = typename MM<T>::vec_t;
@@ -368,6 +372,40 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
   }
 
   const T alpha = (T)g.alpha;
+  if constexpr (EPI == 1) {
+    // column sums of squares of this tile instead of the tile itself.  A lane holds 4 rows x MRN columns of each of
+    // its MRM fragments: rows first in the lane (fragment, then register), then the four lane groups, then the wave rows
+    static_assert(NW == 4 && BT == 128, "the reduction is laid out for 2 x 2 waves of 64 x 64");
+    double cs[MRN];
+#pragma unroll
+    for (int j = 0; j < MRN; ++j) {
+      double sq = 0.0;
+#pragma unroll
+      for (int i = 0; i < MRM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          double v;
+          if constexpr (TWO_LEVEL)
+            v = (double)(alpha * (acc[i][j][r] + acc2[i][j][r]));
+          else
+            v = (double)(alpha * acc[i][j][r]);
+          sq = fma(v, v, sq);
+        }
+      sq += __shfl_xor(sq, 16, 64);
+      sq += __shfl_xor(sq, 32, 64);
+      cs[j] = sq;
+    }
+    double* red = reinterpret_cast<double*>(smem);  // [2 wave rows][BT columns]; the k-loop is done with the stages
+    __syncthreads();
+    if ((lane >> 4) == 0) {
+#pragma unroll
+      for (int j = 0; j < MRN; ++j) red[wr * BT + wc * WTN + j * 16 + (lane & 15)] = cs[j];
+    }
+    __syncthreads();
+    if (t < BT) g.colsq[((size_t)by * g.tiles_m + ti) * (size_t)g.N + n0 + t] = red[t] + red[BT + t];
+    __syncthreads();  // (a persistent block restages LDS for its next tile)
+    return;
+  }
   // beta = 1: the old values of one accumulator row (MRN x 4 per lane) are loaded as a batch before
   // any store of that row -- interleaved load/add/store through the same pointer serialises into
   // MRM x MRN x 4 dependent memory round trips (the 64-tile syrk of a 256-node took 12 us
@@ -408,7 +446,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
   }
 }
 
-template <typename T, bool AKM, bool BKM, int BT, int NW>
+template <typename T, bool AKM, bool BKM, int BT, int NW, int EPI = 0>
 __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) T smem[4 * opsz_of<T>(BT)];
   int bx = blockIdx.x, by = blockIdx.y;
@@ -426,7 +464,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(GemmArgs g) {
       by = wk / (int)gridDim.x;
     }
   }
-  gemm_tile<T, AKM, BKM, BT, NW>(g, bx, by, smem);
+  gemm_tile<T, AKM, BKM, BT, NW, 0, EPI>(g, bx, by, smem);
 }
 
 // Two independent products in ONE launch (plan.h: the syrk A22 -= T21 T21^T and the inverse product U = T21 W11 of
@@ -462,7 +500,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_dual_kernel(GemmArgs g1,
 // others when its own is empty.  Blocks that share an L2 then work on tiles of the same
 // sample, consecutive tiles of a sample share an operand panel, and the panel is read
 // from HBM / Infinity Cache once per XCD instead of once per tile.
-template <typename T, bool AKM, bool BKM, int BT, int NW>
+template <typename T, bool AKM, bool BKM, int BT, int NW, int EPI = 0>
 __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_persist_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) T smem[4 * opsz_of<T>(BT)];
   __shared__ int next_tile;
@@ -475,7 +513,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_persist_kernel(GemmArgs 
       const int idx = __builtin_amdgcn_readfirstlane(next_tile);
       __syncthreads();  // everyone holds idx before thread 0 may overwrite it; also fences the LDS stages
       if (idx >= total) break;
-      gemm_tile<T, AKM, BKM, BT, NW>(g, idx / g.batch, idx % g.batch, smem);
+      gemm_tile<T, AKM, BKM, BT, NW, 0, EPI>(g, idx / g.batch, idx % g.batch, smem);
     }
     return;
   }
@@ -511,7 +549,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_persist_kernel(GemmArgs 
       // into every XCD's L2 at once: cfg3 W^T W 5.58 -> 5.36 ms, step 20.9 -> 20.4 ms; cfg5 552 -> 531 ms.)
       const int ntq = total / nsq;
       const int sq = idx / ntq, tq = idx - sq * ntq;
-      gemm_tile<T, AKM, BKM, BT, NW>(g, cls + tq * nclass, smp + NQ * sq, smem);
+      gemm_tile<T, AKM, BKM, BT, NW, 0, EPI>(g, cls + tq * nclass, smp + NQ * sq, smem);
     }
   }
 }
@@ -596,6 +634,29 @@ inline hipError_t launch_gemm_dual_small(hipStream_t st, GemmArgs g1, GemmArgs g
   if (n[0] + n[1] <= 0 || batch <= 0) return hipSuccess;
   hipLaunchKernelGGL((gemm_dual_kernel<T, false, false, false, true, BT, 4>), dim3(n[0] + n[1], batch), dim3(256), 0, st,
                      g1, g2, n[0]);
+  return hipGetLastError();
+}
+
+// V = A B with A m-major and B k-major (predict: W Ks), 128-tiles, NOT stored: g.colsq receives the column sums of
+// squares per tile row (gemm_tile, EPI = 1).  Persistent XCD-affine queues when the launch has more tiles than block
+// slots and `ctr` (CTR_STRIDE zeroed counters) is given.
+template <typename T>
+inline hipError_t launch_gemm_colsq(hipStream_t st, GemmArgs g, int batch, int* ctr) {
+  constexpr int BT = 128;
+  g.tiles_m = g.M / BT;
+  g.tiles_n = g.N / BT;
+  g.flags = g_gemm_flags;
+  g.lower_only = 0;
+  g.ntiles = g.tiles_m * g.tiles_n;
+  if (g.ntiles <= 0 || batch <= 0) return hipSuccess;
+  g.batch = batch;
+  g.ctr = ctr;
+  g.rsv = nullptr;
+  const int cap = g_block_slots - g_persist_spare;
+  if (ctr && cap > 0 && (long long)g.ntiles * batch > cap)
+    hipLaunchKernelGGL((gemm_persist_kernel<T, false, true, BT, 4, 1>), dim3(cap), dim3(256), 0, st, g);
+  else
+    hipLaunchKernelGGL((gemm_kernel<T, false, true, BT, 4, 1>), dim3(g.ntiles, batch), dim3(256), 0, st, g);
   return hipGetLastError();
 }
 

@@ -1629,6 +1629,7 @@ int rhs_products(gpc_post* po, int mode, const double* xa, const double* xb, int
     }
     T* Ks = c->ks.as<T>();
     T* V = c->vb.as<T>();
+    bool fused_mu = false;
     if (mode == 0) {
       long long tot = (long long)npad * D;
       if (!resident)
@@ -1637,8 +1638,12 @@ int rhs_products(gpc_post* po, int mode, const double* xa, const double* xb, int
       tot = (long long)mpad * D;
       hipLaunchKernelGGL(scale_x_kernel, dim3((unsigned)((tot + 255) / 256), cnt), dim3(256), 0, st,
                          (const double*)d_xa, M, mpad, D, mulb, divb, c->xss.as<double>());
-      hipLaunchKernelGGL((cross_kernel<T>), dim3(mpad / 64, npad / 4, cnt), dim3(64, 4), 0, st, po->cd, xsb,
-                         c->xss.as<double>(), spb, N, npad, M, mpad, Ks, sKs);
+      // cross covariances in 64 x 64 tiles with the mean product fused in (covfun.h: cross_tile_kernel)
+      HIPCHK(c, c->dbg2.ensure((size_t)cnt * (npad / CT) * mpad * 8));
+      GPC_COV_DISPATCH(cross_tile_kernel, T, po->cd, dim3(mpad / CT, npad / CT, cnt), dim3(256), 0, st, po->cd, xsb,
+                       (const double*)c->xss.as<double>(), spb, (const double*)(po->alpha.as<double>() + (size_t)s0 * npad),
+                       npad, N, npad, M, mpad, Ks, sKs, c->dbg2.as<double>());
+      fused_mu = true;
       if (full)
         hipLaunchKernelGGL((cross_kernel<T>), dim3(mpad / 64, mpad / 4, cnt), dim3(64, 4), 0, st, po->cd,
                            c->xss.as<double>(), c->xss.as<double>(), spb, M, mpad, M, mpad, c->kss.as<T>(), sKss);
@@ -1662,8 +1667,12 @@ int rhs_products(gpc_post* po, int mode, const double* xa, const double* xb, int
     }
     double* d_mu = c->pout.as<double>();
     double* d_v = d_mu + (size_t)chunk * mpad;
-    hipLaunchKernelGGL((colsum_vec_kernel<T>), dim3(mpad / 64, cnt), dim3(256), 0, st, (const T*)Ks, sKs, mpad,
-                       po->alpha.as<double>() + (size_t)s0 * npad, npad, npad, mpad, d_mu);
+    if (fused_mu)
+      hipLaunchKernelGGL(colpart_reduce_kernel, dim3((mpad + 255) / 256, cnt), dim3(256), 0, st,
+                         (const double*)c->dbg2.as<double>(), npad / CT, mpad, d_mu);
+    else
+      hipLaunchKernelGGL((colsum_vec_kernel<T>), dim3(mpad / 64, cnt), dim3(256), 0, st, (const T*)Ks, sKs, mpad,
+                         po->alpha.as<double>() + (size_t)s0 * npad, npad, npad, mpad, d_mu);
     HIPCHK(c, hipGetLastError());
     // runs of equal L_chol share launches
     int a = 0;
@@ -1690,6 +1699,22 @@ int rhs_products(gpc_post* po, int mode, const double* xa, const double* xb, int
       g.lower_only = 0;
       g.A = (lch ? po->W.as<T>() : po->A.as<T>()) + (size_t)(s0 + a) * sM;  // V = W R | G = L R
       g.khi = lch ? KHI_ROW : KHI_FULL;
+      if (lch && !full) {
+        // the variance needs the column sums of squares of V only: the product's epilogue forms them per tile row and V
+        // is never written (gemm.h: EPI = 1); a small reduction over the tile rows follows
+        const int tm = npad / TILE;
+        HIPCHK(c, c->dbg3.ensure((size_t)cnt * tm * mpad * 8));  // (the whole chunk: no reallocation between runs)
+        int* qctr = c->tile_ctr.as<int>() + (size_t)gpc_ctx::MAXG * gpc_ctx::CTR_PER_GROUP;
+        HIPCHK(c, hipMemsetAsync(qctr, 0, CTR_STRIDE * sizeof(int), st));
+        HIPCHK(c, hipEventRecord(c->ev[1], st));
+        g.colsq = c->dbg3.as<double>();
+        HIPCHK(c, launch_gemm_colsq<T>(st, g, len, qctr));
+        if (e == cnt) HIPCHK(c, hipEventRecord(c->ev[2], st));
+        hipLaunchKernelGGL(colpart_reduce_kernel, dim3((mpad + 255) / 256, len), dim3(256), 0, st,
+                           (const double*)c->dbg3.as<double>(), tm, mpad, d_v + (size_t)a * mpad);
+        a = e;
+        continue;
+      }
       HIPCHK(c, launch_gemm<T>(st, g, false, true, len));
       if (e == cnt) HIPCHK(c, hipEventRecord(c->ev[2], st));  // (several runs: the first launch to the last, with what lies between)
       const T* left = lch ? (const T*)(V + (size_t)a * sKs) : (const T*)(Ks + (size_t)a * sKs);
