@@ -349,14 +349,15 @@ template <int KIND, int DEG>
 __device__ __forceinline__ void build_tile32(const CovDesc& cd, const double* __restrict__ Xs_all,
                                              const double* __restrict__ sp_all, const double* __restrict__ dvec_all,
                                              int n, int npad, float* __restrict__ A_all, long long sA, int lda,
-                                             int tile, int b, float* __restrict__ xi, float* __restrict__ xj) {
+                                             int tile, int b, int bs, float* __restrict__ xi, float* __restrict__ xj) {
+  // bs: the sample index into sp_all / dvec_all (= b, except where the caller holds one sample's copies: bs = 0)
   const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
   int ti, tj;
   lower_tile(tile, ti, tj);
   const int i0 = ti * CT, j0 = tj * CT;
   const double* Xs = Xs_all + (size_t)b * npad * cd.D;
-  const double* sp = sp_all + (size_t)b * SP_STRIDE;
-  const double* dvec = dvec_all + (size_t)b * npad;
+  const double* sp = sp_all + (size_t)bs * SP_STRIDE;
+  const double* dvec = dvec_all + (size_t)bs * npad;
   float* A = A_all + (size_t)b * sA;
   float r2[4][4];
   tile_r2_32(r2, xi, xj, Xs, cd.D, i0, j0, t, tx, ty);
@@ -507,12 +508,12 @@ __device__ __forceinline__ void trace_tile32(const CovDesc& cd, const double* __
 // grid = (lower tiles of npad/64, batch)
 // ---------------------------------------------------------------------------------
 template <typename T, int KIND, int DEG>
-__device__ __forceinline__ void build_tile(const CovDesc& cd, const double* __restrict__ Xs_all,
-                                           const double* __restrict__ sp_all, const double* __restrict__ dvec_all,
-                                           int n, int npad, T* __restrict__ A_all, long long sA, int lda, int tile,
-                                           int b, double (*xi)[DCH + 1], double (*xj)[DCH + 1]) {
+__device__ __forceinline__ void build_tile_at(const CovDesc& cd, const double* __restrict__ Xs_all,
+                                              const double* __restrict__ sp_all, const double* __restrict__ dvec_all,
+                                              int n, int npad, T* __restrict__ A_all, long long sA, int lda, int tile,
+                                              int b, int bs, double (*xi)[DCH + 1], double (*xj)[DCH + 1]) {
   if constexpr (sizeof(T) == 4) {  // fp32 mode: the native fp32 functor (the LDS arrays are reused as float images)
-    build_tile32<KIND, DEG>(cd, Xs_all, sp_all, dvec_all, n, npad, A_all, sA, lda, tile, b,
+    build_tile32<KIND, DEG>(cd, Xs_all, sp_all, dvec_all, n, npad, A_all, sA, lda, tile, b, bs,
                             reinterpret_cast<float*>(&xi[0][0]), reinterpret_cast<float*>(&xj[0][0]));
     return;
   }
@@ -521,8 +522,8 @@ __device__ __forceinline__ void build_tile(const CovDesc& cd, const double* __re
   lower_tile(tile, ti, tj);
   const int i0 = ti * CT, j0 = tj * CT;
   const double* Xs = Xs_all + (size_t)b * npad * cd.D;
-  const double* sp = sp_all + (size_t)b * SP_STRIDE;
-  const double* dvec = dvec_all + (size_t)b * npad;
+  const double* sp = sp_all + (size_t)bs * SP_STRIDE;
+  const double* dvec = dvec_all + (size_t)bs * npad;
   T* A = A_all + (size_t)b * sA;
 
   double r2[4][4];
@@ -545,6 +546,14 @@ __device__ __forceinline__ void build_tile(const CovDesc& cd, const double* __re
       }
       A[(size_t)i * lda + j] = (T)v;
     }
+}
+
+template <typename T, int KIND, int DEG>
+__device__ __forceinline__ void build_tile(const CovDesc& cd, const double* __restrict__ Xs_all,
+                                           const double* __restrict__ sp_all, const double* __restrict__ dvec_all,
+                                           int n, int npad, T* __restrict__ A_all, long long sA, int lda, int tile,
+                                           int b, double (*xi)[DCH + 1], double (*xj)[DCH + 1]) {
+  build_tile_at<T, KIND, DEG>(cd, Xs_all, sp_all, dvec_all, n, npad, A_all, sA, lda, tile, b, b, xi, xj);
 }
 
 // grid = (number of lower tiles to build, batch); tile0 = index of the first one

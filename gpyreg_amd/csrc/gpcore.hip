@@ -99,15 +99,30 @@ struct XferDesc {
   double* xs = nullptr;
   int n = 0, npad = 0, D = 0, cnt = 0;
 };
-__global__ __launch_bounds__(256) void xfer_kernel(XferDesc d) {
-  const unsigned long long gt = (unsigned long long)blockIdx.x * 256 + threadIdx.x, stride = (unsigned long long)gridDim.x * 256;
-  for (int k = 0; k < d.nseg; ++k) {
-    unsigned long long* dst = reinterpret_cast<unsigned long long*>(d.seg[k].dst);
-    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(d.seg[k].src);
-    for (unsigned long long i = gt; i < d.seg[k].n8; i += stride) dst[i] = src[i];
+__device__ __forceinline__ void xfer_body_noxs(const XferDesc& d, unsigned long long gt, unsigned long long stride) {
+  // the segments as ONE index space: a thread's words are independent loads from (mapped) host memory, all in flight
+  // together -- a loop per segment made nseg dependent PCIe round trips of ~2.5 us each out of a small upload
+  unsigned long long total = 0;
+  for (int k = 0; k < d.nseg; ++k) total += d.seg[k].n8;
+  // ... dealt to the blocks in contiguous chunks of equal size (a small upload read by the first block alone queues
+  // behind that one CU's outstanding host reads: 8 us for 2.6 KB against 3.6 us for a third of it)
+  const unsigned long long nblk = stride / 256, blk = gt / 256, lt = gt % 256;
+  const unsigned long long chunk = (total + nblk - 1) / nblk;
+  const unsigned long long hi = chunk * (blk + 1) < total ? chunk * (blk + 1) : total;
+  for (unsigned long long i = chunk * blk + lt; i < hi; i += 256) {
+    unsigned long long j = i;
+    int k = 0;
+    while (j >= d.seg[k].n8) {
+      j -= d.seg[k].n8;
+      ++k;
+    }
+    reinterpret_cast<unsigned long long*>(d.seg[k].dst)[j] = reinterpret_cast<const unsigned long long*>(d.seg[k].src)[j];
   }
   unsigned long long* z = reinterpret_cast<unsigned long long*>(d.zero);
   for (unsigned long long i = gt; i < d.zero8; i += stride) z[i] = 0ull;
+}
+__device__ __forceinline__ void xfer_body(const XferDesc& d, unsigned long long gt, unsigned long long stride) {
+  xfer_body_noxs(d, gt, stride);
   if (d.xs) {
     const unsigned long long per = (unsigned long long)d.npad * d.D, tot = per * d.cnt;
     for (unsigned long long q = gt; q < tot; q += stride) {
@@ -118,6 +133,78 @@ __global__ __launch_bounds__(256) void xfer_kernel(XferDesc d) {
       d.xs[q] = v;
     }
   }
+}
+__global__ __launch_bounds__(256) void xfer_kernel(XferDesc d) {
+  xfer_body(d, (unsigned long long)blockIdx.x * 256 + threadIdx.x, (unsigned long long)gridDim.x * 256);
+}
+
+// Problems that are one 128 x 128 leaf (N <= 128): the upload kernel and the covariance build in ONE launch.
+// grid = (3 lower 64-tiles, samples).  Every block takes its share of the gathered upload (xfer_body: the segments land
+// in their device buffers for the kernels that follow), then scales the 128 rows of its sample's inputs by itself --
+// every block of a sample writes the same values: each needs rows of both halves -- and builds its tile, reading the
+// per-sample scalars and the diagonal term from the STAGED HOST COPIES (`sp_h`, `dvec_h`: mapped pinned memory; the
+// device copies are being written by other blocks of this very launch and are not ordered against this read).
+template <typename T, int KIND, int DEG>
+__global__ __launch_bounds__(256) void small_front_kernel(XferDesc d, CovDesc cd, const double* __restrict__ sp_h,
+                                                          const double* __restrict__ dvec_h, T* __restrict__ A_all,
+                                                          long long sA) {
+  __shared__ double xi[CT][DCH + 1];
+  __shared__ double xj[CT][DCH + 1];
+  // this sample's host-resident inputs, fetched ONCE: a load from mapped host memory is a PCIe round trip (~2.5 us),
+  // and the code below would otherwise make four dependent ones (scaling factors, scalars, diagonal term)
+  constexpr int DL = 64;  // input dimensions whose scaling factors are kept in LDS (more: read from the host copy)
+  __shared__ double h_sp[SP_STRIDE], h_dvec[TILE], h_mul[DL], h_dv[DL];
+  const int b = blockIdx.y, t = threadIdx.x;
+#ifdef GPC_FRONT_TRACE
+  long long ts[6];
+  ts[0] = wall_clock64();
+#endif
+  const bool dl = d.D <= DL;
+  double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+  // the diagonal term is read by the diagonal tiles only (tile 0: rows 0..63, tile 2: rows 64..127)
+  const int drow = blockIdx.x == 2 ? CT : 0;
+  const bool dg = blockIdx.x != 1 && t < CT;
+  if (dg) v0 = dvec_h[(size_t)b * TILE + drow + t];
+  if (t < SP_STRIDE) v1 = sp_h[(size_t)b * SP_STRIDE + t];
+  if (dl && t < d.D) {
+    v2 = d.mul[(size_t)b * d.D + t];
+    v3 = d.dv[(size_t)b * d.D + t];
+  }
+  xfer_body_noxs(d, ((unsigned long long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x,
+                 (unsigned long long)gridDim.x * gridDim.y * 256);
+#ifdef GPC_FRONT_TRACE
+  ts[1] = wall_clock64();
+#endif
+  if (dg) h_dvec[drow + t] = v0;
+  if (t < SP_STRIDE) h_sp[t] = v1;
+  if (dl && t < d.D) {
+    h_mul[t] = v2;
+    h_dv[t] = v3;
+  }
+  __syncthreads();
+#ifdef GPC_FRONT_TRACE
+  ts[2] = wall_clock64();
+#endif
+  double* xs = d.xs + (size_t)b * d.npad * d.D;
+  const double* mulp = dl ? h_mul : d.mul + (size_t)b * d.D;
+  const double* dvp = dl ? h_dv : d.dv + (size_t)b * d.D;
+  for (int q = t; q < d.npad * d.D; q += 256) {
+    const int i = q / d.D, h = q - i * d.D;
+    xs[q] = i < d.n ? d.X[(size_t)i * d.D + h] * mulp[h] / dvp[h] : 0.0;
+  }
+  __syncthreads();  // (a block reads back only what it wrote itself)
+#ifdef GPC_FRONT_TRACE
+  ts[3] = wall_clock64();
+#endif
+  // sample index 0 for the scalars and the diagonal term: the LDS copies hold this block's sample only
+  build_tile_at<T, KIND, DEG>(cd, d.xs, h_sp, h_dvec, d.n, d.npad, A_all, sA, d.npad, blockIdx.x, b, 0, xi, xj);
+#ifdef GPC_FRONT_TRACE
+  __syncthreads();
+  ts[4] = wall_clock64();
+  if (t == 0 && b == 0)
+    printf("front tile %d: copy %lld  lds %lld  xs %lld  build %lld  (10 ns ticks)\n", (int)blockIdx.x, ts[1] - ts[0],
+           ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3]);
+#endif
 }
 
 struct PinBuf {
@@ -234,6 +321,25 @@ struct PinBuf {
     upd.nseg = 0;
     return hipGetLastError();
   }
+  // flush_up without the launch: the fallback copies go out, `out` receives the descriptor of the gathered segments
+  // (the caller's own kernel moves them: small_front_kernel)
+  hipError_t take_up(hipStream_t st, void* zero, size_t zero_bytes, XferDesc& out) {
+    for (Pending& q : up_fallback) {
+      hipError_t e = up(q.dst, q.src, q.n, st);
+      if (e != hipSuccess) return e;
+    }
+    up_fallback.clear();
+    if (zero_bytes % 8) {
+      hipError_t e = hipMemsetAsync(zero, 0, zero_bytes, st);
+      if (e != hipSuccess) return e;
+      zero_bytes = 0;
+    }
+    upd.zero = zero;
+    upd.zero8 = zero_bytes / 8;
+    out = upd;
+    upd.nseg = 0;
+    return hipSuccess;
+  }
   // dst: host; the data lands there at finish()
   hipError_t gather(void* dst, const void* src, size_t n, hipStream_t st) {
     if (n == 0) return hipSuccess;
@@ -297,6 +403,7 @@ struct gpc_ctx {
   int rl_panel = 0;
   int rl_ahead_max = 8;  // look-ahead (side stream + reserved CUs) only for batches with S (npad/4096)^3 <= this
   int stable = 0;        // option: every factorization in stable mode (plan.h), not only the jitter retries
+  int small_path = 1;    // option: problems of one 128 x 128 leaf take the two-launch pipeline (Pipe::small_section)
   int check_queues = 0;  // debug option: verify after every pipeline that the tile queues of its persistent launches were drained
   hipEvent_t ev_up = nullptr, ev_done[MAXG] = {};
   int groups = 2;
@@ -992,6 +1099,98 @@ struct Pipe {
   bool prescaled = false;  // the transfer kernel of this chunk has written the scaled inputs (run())
   int lauum_n[gpc_ctx::MAXG + 1] = {};
 
+  // The pipeline of a chunk whose matrices are single 128 x 128 leaves (see run()).  A, W, Tm point at the chunk's slot.
+  int small_section(int s0, int cnt, const double* hsp, const double* hmul, const double* hdv, const double* hdvec,
+                    const double* rsrc, size_t scal_bytes, HostClock& hc) {
+    Batch& b = *B;
+    const int npad = b.npad, N = b.N, D = b.D, Pn = P();
+    hipStream_t st = c->st;
+    double* d_logdet = c->scal.as<double>();
+    double* d_quad = d_logdet + cnt;
+    int* d_info = reinterpret_cast<int*>(d_quad + cnt);
+    double* land = mode == MODE_NLL ? static_cast<double*>(c->pin.alloc(scal_bytes)) : nullptr;
+    XferDesc u;
+    HIPCHK(c, c->pin.take_up(st, c->scal.p, scal_bytes, u));
+    u.X = c->dX.as<double>();
+    u.mul = hmul;
+    u.dv = hdv;
+    u.xs = c->xs.as<double>();
+    u.n = N;
+    u.npad = npad;
+    u.D = D;
+    u.cnt = cnt;
+    HIPCHK(c, hipEventRecord(c->ev[1], st));
+    GPC_COV_DISPATCH(small_front_kernel, T, b.cd, dim3(3, cnt), dim3(256), 0, st, u, b.cd, hsp, hdvec, A, sM);
+    hipLaunchKernelGGL((leaf_solve_kernel<T>), dim3(cnt), dim3(256), 0, st, A, sM, npad, W, sM, npad, d_logdet, d_info, N,
+                       gpc::g_leaf_fault, rsrc, c->zvec.as<double>(), d_quad,
+                       mode == MODE_GRAD ? c->avec.as<double>() : nullptr, (const double*)c->spb.as<double>(),
+                       (int)SP_STRIDE, (int)SP_SL, land, cnt);
+    HIPCHK(c, hipGetLastError());
+    c->last_flops += (2.0 / 3.0) * TILE * (double)TILE * TILE * cnt;
+    if (mode == MODE_GRAD) {
+      Factor<T> F;
+      F.st = st;
+      F.batch = cnt;
+      F.npad = npad;
+      F.A = A;
+      F.W = W;
+      F.Tm = Tm;
+      F.sA = F.sW = F.sT = sM;
+      F.lauum(Tm, sM);
+      HIPCHK(c, F.err);
+      c->last_flops += F.flops;
+      HIPCHK(c, hipEventRecord(c->ev[2], st));
+      const int t64 = npad / CT, ntl = t64 * (t64 + 1) / 2;
+      double* parts = c->parts.as<double>();
+      double* diagq = c->diagq.as<double>();
+      GPC_COV_DISPATCH(trace_kernel, T, b.cd, dim3(ntl, cnt), dim3(256), 4 * (((Pn + 3) & ~3) + 4) * sizeof(double), st, b.cd,
+                       (const double*)c->xs.as<double>(), (const double*)c->spb.as<double>(),
+                       (const double*)c->avec.as<double>(), N, npad, (const T*)Tm, sM, npad, parts, ntl, diagq);
+      const int mN = mean_N > 0 ? mean_N : 0, nN = (noise_N > 0 && b.vec_noise) ? noise_N : 0;
+      hipLaunchKernelGGL(grad_tail_kernel, dim3(Pn + mN + nN, cnt), dim3(256), 0, st, (const double*)parts, ntl, Pn,
+                         c->gout.as<double>(), mN ? (const double*)c->dmb.as<double>() : nullptr, N, mN,
+                         (const double*)c->avec.as<double>(), mN ? c->mg.as<double>() : nullptr,
+                         nN ? (const double*)c->dsn2b.as<double>() : nullptr, nN, (const double*)diagq,
+                         nN ? c->ng.as<double>() : nullptr, npad);
+      HIPCHK(c, hipGetLastError());
+    } else {
+      HIPCHK(c, hipEventRecord(c->ev[2], st));
+    }
+    HIPCHK(c, hipEventRecord(c->ev[3], st));
+    hc.lap("launch");
+    std::vector<double> hscal(scal_bytes / 8);
+    if (mode == MODE_GRAD) {
+      HIPCHK(c, c->pin.gather(hscal.data(), d_logdet, scal_bytes, st));
+      HIPCHK(c, c->pin.gather(&G[(size_t)s0 * Pn], c->gout.p, (size_t)cnt * Pn * 8, st));
+      if (mean_N > 0) HIPCHK(c, c->pin.gather(&mg[(size_t)s0 * mean_N], c->mg.p, (size_t)cnt * mean_N * 8, st));
+      if (noise_N > 0 && b.vec_noise)
+        HIPCHK(c, c->pin.gather(&ng[(size_t)s0 * noise_N], c->ng.p, (size_t)cnt * noise_N * 8, st));
+      HIPCHK(c, c->pin.flush_down(st));
+    } else if (!land) {
+      HIPCHK(c, hipMemcpyAsync(hscal.data(), d_logdet, scal_bytes, hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(c, hipStreamSynchronize(st));
+    c->pin.finish();
+    if (land) memcpy(hscal.data(), land, scal_bytes);
+    memcpy(&logdet[s0], hscal.data(), (size_t)cnt * 8);
+    memcpy(&quad[s0], hscal.data() + cnt, (size_t)cnt * 8);
+    const int* hinfo = reinterpret_cast<const int*>(hscal.data() + 2 * (size_t)cnt);
+    hc.lap("d2h+sync");
+    for (int i = 0; i < cnt; ++i) b.info[s0 + i] = hinfo[i];
+    for (int i = 0; i < cnt; ++i)
+      if (hinfo[i] & LEAF_TIMEOUT) {
+        c->err = "internal error: a hand-off between the waves of a 128 x 128 leaf factorization timed out (sample " +
+                 std::to_string(s0 + i) + "); the results of this call are invalid";
+        return -3;
+      }
+    float t03 = 0, t12 = 0;
+    (void)hipEventElapsedTime(&t03, c->ev[0], c->ev[3]);
+    (void)hipEventElapsedTime(&t12, c->ev[1], c->ev[2]);
+    c->ms_total += t03;
+    c->ms_factor += t12;
+    return 0;
+  }
+
   // run the device pipeline for samples [s0, s0+cnt) whose matrices start at slot `slot`.
   // The chunk is split into sample groups on separate HIP streams: the latency-bound
   // phases of one group (leaves, deep recursion levels) run beside the throughput-bound
@@ -1050,7 +1249,7 @@ struct Pipe {
     c->pin.begin_gather();
     auto up = [&](void* dst, const void* src, size_t n) { return c->pin.stage(dst, src, n); };
     HIPCHK(c, hipEventRecord(c->ev[0], st));
-    up(c->spb.p, &b.sp[(size_t)s0 * SP_STRIDE], (size_t)cnt * SP_STRIDE * 8);
+    const void* hsp = up(c->spb.p, &b.sp[(size_t)s0 * SP_STRIDE], (size_t)cnt * SP_STRIDE * 8);
     const void* hmul = up(c->mulb.p, &b.mul[(size_t)s0 * D], (size_t)cnt * D * 8);
     const void* hdv = up(c->divb.p, &b.dv[(size_t)s0 * D], (size_t)cnt * D * 8);
     // the scaled inputs of the whole chunk ride in the transfer kernel (device_section then starts with the build)
@@ -1066,13 +1265,42 @@ struct Pipe {
       u.D = D;
       u.cnt = cnt;
     }
-    up(c->dvec.p, &b.dvec[(size_t)s0 * npad], cnt * vb);
-    up(c->rvec.p, &b.r[(size_t)s0 * npad], cnt * vb);
+    // Problems that are ONE 128 x 128 leaf take a pipeline of their own (small_section below); there the diagonal term
+    // is read from its staged host copy by the build itself and needs no device copy
+    const bool small_ok = c->small_path && npad == TILE && mode != MODE_POST && !kmode() && !(stable || c->stable) &&
+                          gpc::g_leaf_version == 5 && hsp && hmul && hdv;
+    const void* hdvec = nullptr;
+    if (small_ok)
+      if (void* h = c->pin.alloc(cnt * vb)) {
+        memcpy(h, &b.dvec[(size_t)s0 * npad], cnt * vb);
+        hdvec = h;
+      }
+    if (!hdvec) up(c->dvec.p, &b.dvec[(size_t)s0 * npad], cnt * vb);
+    // ... and r = y - m is read from its staged copy by the kernel that needs it (leaf_solve_kernel, at its start:
+    // the round trip to host memory hides under the factorization)
+    const void* hr = nullptr;
+    if (hdvec)
+      if (void* h = c->pin.alloc(cnt * vb)) {
+        memcpy(h, &b.r[(size_t)s0 * npad], cnt * vb);
+        hr = h;
+      }
+    if (!hr) up(c->rvec.p, &b.r[(size_t)s0 * npad], cnt * vb);
     if (mode == MODE_GRAD && mean_N > 0) up(c->dmb.p, dm + (size_t)s0 * N * mean_N, (size_t)cnt * N * mean_N * 8);
     if (mode == MODE_GRAD && noise_N > 0 && b.vec_noise)
       up(c->dsn2b.p, dsn2 + (size_t)s0 * N * noise_N, (size_t)cnt * N * noise_N * 8);
+    // Problems that are ONE 128 x 128 leaf (N <= 128; decided by the problem size only, so that a row of a batch carries
+    // the bits of its single evaluation): upload + build in one launch, leaf + both triangular products in one launch,
+    // and an evaluation without gradient writes its three scalars straight into the host's landing block.  Two
+    // launches instead of six (NLL), six instead of ten (gradient).  gpc_set_option("small_path", 0) turns it off.
+    const size_t scal_bytes0 = (((size_t)cnt * (2 * sizeof(double) + sizeof(int))) + 7) & ~(size_t)7;
+    if (small_ok && hdvec) {
+      int rc = small_section(s0, cnt, static_cast<const double*>(hsp), static_cast<const double*>(hmul),
+                             static_cast<const double*>(hdv), static_cast<const double*>(hdvec),
+                             hr ? static_cast<const double*>(hr) : (const double*)c->rvec.as<double>(), scal_bytes0, hc);
+      return rc;
+    }
     // one kernel: every staged segment and the zeroing of [logdet | quad | info] (padded to whole words)
-    HIPCHK(c, c->pin.flush_up(st, c->scal.p, (((size_t)cnt * (2 * sizeof(double) + sizeof(int))) + 7) & ~(size_t)7));
+    HIPCHK(c, c->pin.flush_up(st, c->scal.p, scal_bytes0));
 
     hc.lap("h2d");
     int groups = c->groups;
@@ -2142,6 +2370,7 @@ int gpc_create(int device, gpc_ctx** out) {
     return -1;
   }
   if (const char* e = getenv("GPC_LEAF")) gpc::g_leaf_version = atoi(e) == 3 ? 3 : 5;
+  if (const char* e = getenv("GPC_SMALL_PATH")) c->small_path = atoi(e) != 0;
   if (const char* e = getenv("GPC_GRAPH_MAX_NPAD")) c->graph_max_npad = atoi(e);
   if (const char* e = getenv("GPC_RL_PANEL")) c->rl_panel = atoi(e) <= 0 ? 0 : std::max(TILE, (atoi(e) / TILE) * TILE);
   if (const char* e = getenv("GPC_NLL_BLOCK")) c->nll_block = atoi(e) < 0 ? -1 : (atoi(e) == 0 ? 0 : std::max(TILE, (atoi(e) / TILE) * TILE));
@@ -2617,6 +2846,8 @@ int gpc_set_option(gpc_ctx* c, const char* name, int value) {
     c->rl_panel = value <= 0 ? 0 : std::max(TILE, (value / TILE) * TILE);
   else if (n == "stable")  // every factorization in stable mode (refined panel solves, plan.h), not only the jitter retries
     c->stable = value != 0;
+  else if (n == "small_path")  // 0: problems of one leaf take the general pipeline too (A/B and cross-checks)
+    c->small_path = value != 0;
   else if (n == "check_queues")  // debug: verify the tile queues of persistent launches after every pipeline
     c->check_queues = value != 0;
   else if (n == "start_mult_log10")  // test hook: first jitter multiplier 10^value
@@ -2643,6 +2874,7 @@ int gpc_get_option(gpc_ctx* c, const char* name, int* value) {
   else if (n == "rl_ahead_max") *value = c->rl_ahead_max;
   else if (n == "rl_panel") *value = c->rl_panel;
   else if (n == "stable") *value = c->stable;
+  else if (n == "small_path") *value = c->small_path;
   else if (n == "check_queues") *value = c->check_queues;
   else FAIL(c, "gpc_get_option: unknown option");
   return 0;

@@ -751,15 +751,15 @@ __device__ __forceinline__ void diag_panel(Shared<T>& sh, T* __restrict__ Ab, in
 }
 }  // namespace leaf5
 
+// The whole pipelined leaf as a device function (all 256 threads of the block call it; the diag wave and the update
+// waves return at different times -- the caller synchronises the block before it reads L / W): leaf5_kernel below, and
+// the fused leaf + solves kernel of problems that ARE one leaf (leaf_solve_kernel).
 template <typename T>
-__global__ __launch_bounds__(256, 1) void leaf5_kernel(T* __restrict__ A, long long sA, int lda, T* __restrict__ W,
-                                                       long long sW, int ldw, int off, double* __restrict__ logdet,
-                                                       int* __restrict__ info, int nvalid, int fault) {
+__device__ __forceinline__ void leaf5_body(leaf5::Shared<T>& sh, T* __restrict__ Ab, int lda, T* __restrict__ Wb, int ldw,
+                                           int off, double* __restrict__ logdet_b, int* __restrict__ info_b, int nvalid,
+                                           int fault) {
   using namespace leaf5;
-  __shared__ Shared<T> sh;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  T* Ab = A + (size_t)blockIdx.x * sA;
-  T* Wb = W + (size_t)blockIdx.x * sW;
   // panels that start at or beyond nvalid are identity padding: L = I, W = I, already in place
   const int np = max(1, min(8, (nvalid + 15) >> 4));
   if (threadIdx.x == 0) {
@@ -795,9 +795,9 @@ __global__ __launch_bounds__(256, 1) void leaf5_kernel(T* __restrict__ A, long l
     }
     lg = wave_sum(lg);
     if (lane == 0) {
-      if (tmo) atomicOr(info + blockIdx.x, LEAF_TIMEOUT);
-      if (bad) atomicCAS(info + blockIdx.x, 0, off + bad);
-      atomicAdd(logdet + blockIdx.x, lg);
+      if (tmo) atomicOr(info_b, LEAF_TIMEOUT);
+      if (bad) atomicCAS(info_b, 0, off + bad);
+      atomicAdd(logdet_b, lg);
     }
     return;
   }
@@ -809,7 +809,103 @@ __global__ __launch_bounds__(256, 1) void leaf5_kernel(T* __restrict__ A, long l
     update_wave<T, 1>(sh, Ab, lda, Wb, ldw, lane, np, bad);
   else
     update_wave<T, 2>(sh, Ab, lda, Wb, ldw, lane, np, bad);
-  if (bad && lane == 0) atomicOr(info + blockIdx.x, LEAF_TIMEOUT);  // a hand-off timed out (never expected)
+  if (bad && lane == 0) atomicOr(info_b, LEAF_TIMEOUT);  // a hand-off timed out (never expected)
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 1) void leaf5_kernel(T* __restrict__ A, long long sA, int lda, T* __restrict__ W,
+                                                       long long sW, int ldw, int off, double* __restrict__ logdet,
+                                                       int* __restrict__ info, int nvalid, int fault) {
+  __shared__ leaf5::Shared<T> sh;
+  leaf5_body<T>(sh, A + (size_t)blockIdx.x * sA, lda, W + (size_t)blockIdx.x * sW, ldw, off, logdet + blockIdx.x,
+                info + blockIdx.x, nvalid, fault);
+}
+
+// ---- problems that are ONE leaf (N <= 128: the single evaluations of the slice sampler and of the optimiser on small
+// training sets, fit's 1024-point design; f_min_fill.py:174-176, slice_sample.py:442): the factorization above and the
+// two triangular products that follow it in ONE launch.  The pipeline used to be leaf | z = W r | z.z (| W^T z partial |
+// its sum): three to four dependent launches of a few microseconds of work each behind a 20 us leaf.  Here the block
+// that factored the matrix reads its own W back (L2 / L1 hot) and finishes the job:
+//     z = W r,   quad = z.z,   alpha = W^T z / sl  (gradient evaluations only)
+// and, for an evaluation without gradient, writes [logdet | quad | info] of its sample straight into the host's pinned
+// landing block (`land`, mapped memory), so no download kernel follows.   grid = (batch), 256 threads.
+template <typename T>
+__global__ __launch_bounds__(256, 1) void leaf_solve_kernel(T* __restrict__ A, long long sA, int lda, T* __restrict__ W,
+                                                            long long sW, int ldw, double* __restrict__ logdet,
+                                                            int* __restrict__ info, int nvalid, int fault,
+                                                            const double* __restrict__ r_all, double* __restrict__ z_all,
+                                                            double* __restrict__ quad_all, double* __restrict__ alpha_all,
+                                                            const double* __restrict__ sp_all, int sp_stride, int sp_sl,
+                                                            double* __restrict__ land, int cnt) {
+  using vec_t = typename MM<T>::vec_t;
+  constexpr int VEC = MM<T>::VEC;
+  __shared__ leaf5::Shared<T> sh;
+  __shared__ double zs[TILE], red[2][TILE], sh4[4];
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+  T* Wb = W + (size_t)b * sW;
+  // r first (it may live in mapped host memory: the round trip hides under the factorization)
+  const double* r = r_all + (size_t)b * TILE;
+  double rk[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) rk[e] = lane * VEC + e < TILE ? r[lane * VEC + e] : 0.0;
+  leaf5_body<T>(sh, A + (size_t)b * sA, lda, Wb, ldw, 0, logdet + b, info + b, nvalid, fault);
+  __syncthreads();  // L and W of this block are in memory (and visible to the block: __syncthreads orders global stores)
+  // z_i = sum_k W[i][k] r[k]: one wave per row, all 32 rows of a wave in flight at once (one L2 round trip; W is zero
+  // above the diagonal: whole rows).  The 32 lane sums are folded across the wave by halving: after a step with
+  // offset o a lane keeps half of its values, so 32 values cost 16 + 8 + 4 + 2 + 1 exchanges and one last one.
+  {
+    double s[32];
+    const int i0 = w * 32;
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+      s[u] = 0.0;
+      if (lane * VEC < TILE) {
+        const vec_t wv = *reinterpret_cast<const vec_t*>(Wb + (size_t)(i0 + u) * ldw + lane * VEC);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s[u] = fma((double)wv[e], rk[e], s[u]);
+      }
+    }
+    // halving steps: offsets 32, 16, 8, 4, 2 -- lane bit set: keep the upper half of the values, send the lower
+#pragma unroll
+    for (int n = 32, o = 32; n > 1; n >>= 1, o >>= 1) {
+      const bool up = (lane & o) != 0;
+#pragma unroll
+      for (int u = 0; u < n / 2; ++u) {
+        const double keep = up ? s[u + n / 2] : s[u];
+        const double give = up ? s[u] : s[u + n / 2];
+        s[u] = keep + __shfl_xor(give, o, 64);
+      }
+    }
+    // lane l now holds the sum over the lanes that agree with it in bit 0 of value index bits(l >> 1): one more step
+    const double v = s[0] + __shfl_xor(s[0], 1, 64);
+    // value index: bit 4 from lane bit 5, ..., bit 0 from lane bit 1
+    const int idx = ((lane >> 5) & 1) << 4 | ((lane >> 4) & 1) << 3 | ((lane >> 3) & 1) << 2 | ((lane >> 2) & 1) << 1 |
+                    ((lane >> 1) & 1);
+    if ((lane & 1) == 0) zs[i0 + idx] = v;
+  }
+  __syncthreads();
+  double q = t < TILE ? zs[t] * zs[t] : 0.0;
+  q = block_sum_256(q, sh4);
+  if (t < TILE) z_all[(size_t)b * TILE + t] = zs[t];
+  if (alpha_all) {
+    // alpha_k = sum_{i >= k} W[i][k] z_i / sl: a thread per column and half of the rows (coalesced rows of W)
+    const int k = t & (TILE - 1), h = t >> 7;
+    double s = 0.0;
+    for (int i = 64 * h; i < 64 * h + 64; ++i) s = fma((double)Wb[(size_t)i * ldw + k], zs[i], s);
+    red[h][k] = s;
+    __syncthreads();
+    if (t < TILE) alpha_all[(size_t)b * TILE + t] = (red[0][t] + red[1][t]) / sp_all[(size_t)b * sp_stride + sp_sl];
+  }
+  if (t == 0) {
+    quad_all[b] = q;
+    if (land) {  // [logdet[cnt] | quad[cnt] | info[cnt] (ints)]: this sample's three values, straight to the host
+      const double ld = __hip_atomic_load(logdet + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int inf = __hip_atomic_load(info + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      land[b] = ld;
+      land[cnt + b] = q;
+      reinterpret_cast<int*>(land + 2 * (size_t)cnt)[b] = inf;
+    }
+  }
 }
 
 inline int g_leaf_version = 5;  // 5: pipelined leaf5 (default), 3: the barrier-per-phase leaf3
