@@ -343,15 +343,25 @@ __global__ void pad_load_kernel(const double* __restrict__ src, int n, int npad,
   dst[(size_t)i * npad + j] = (T)v;
 }
 
-// copy the 128 x 128 blocks strictly below the diagonal blocks... generic rect copy:
-// dst[b][r][c] = src[b][r][c] for r < rows, c < cols.  grid = (cols/64, rows/4, batch)
+// dst[b][r][c] = src[b][r][c] for r < rows, c < cols (rows a multiple of 32, cols of 128; 16-byte aligned rows): the
+// L21 blocks of a posterior go back into A with it (plan.h step 6).  A thread moves 16-byte vectors, eight rows in
+// flight (round 4; one element per thread moved cfg3's 2.1 GB per update at 1.1 TB/s: 1.9 ms of a 14.9 ms update).
+// grid = (ceil(cols / (64 VEC)), rows / 32, batch), block = (64, 4)
 template <typename T>
-__global__ void rect_copy_kernel(const T* __restrict__ src, long long sS, int lds_, T* __restrict__ dst,
-                                 long long sD, int ldd, int rows, int cols) {
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  const int r = blockIdx.y * 4 + threadIdx.y;
-  if (r >= rows || c >= cols) return;
-  dst[(size_t)blockIdx.z * sD + (size_t)r * ldd + c] = src[(size_t)blockIdx.z * sS + (size_t)r * lds_ + c];
+__global__ __launch_bounds__(256) void rect_copy_kernel(const T* __restrict__ src, long long sS, int lds_,
+                                                        T* __restrict__ dst, long long sD, int ldd, int rows, int cols) {
+  using vec_t = typename MM<T>::vec_t;
+  constexpr int VEC = MM<T>::VEC;
+  const int c = (blockIdx.x * 64 + threadIdx.x) * VEC;
+  if (c >= cols) return;
+  const int r0 = blockIdx.y * 32 + threadIdx.y;
+  const T* s = src + (size_t)blockIdx.z * sS + c;
+  T* d = dst + (size_t)blockIdx.z * sD + c;
+  vec_t v[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const vec_t*>(s + (size_t)(r0 + 4 * u) * lds_);
+#pragma unroll
+  for (int u = 0; u < 8; ++u) *reinterpret_cast<vec_t*>(d + (size_t)(r0 + 4 * u) * ldd) = v[u];
 }
 
 // register-resident MFMA issue loop: the measured ceiling the roofline is quoted against.

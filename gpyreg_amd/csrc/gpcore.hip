@@ -1108,7 +1108,9 @@ struct Pipe {
     double* d_logdet = c->scal.as<double>();
     double* d_quad = d_logdet + cnt;
     int* d_info = reinterpret_cast<int*>(d_quad + cnt);
-    double* land = mode == MODE_NLL ? static_cast<double*>(c->pin.alloc(scal_bytes)) : nullptr;
+    // (without gradient -- an evaluation, or a posterior: L in A, W and alpha are what it keeps -- the three scalars of a
+    // sample are all that comes back)
+    double* land = mode != MODE_GRAD ? static_cast<double*>(c->pin.alloc(scal_bytes)) : nullptr;
     XferDesc u;
     HIPCHK(c, c->pin.take_up(st, c->scal.p, scal_bytes, u));
     u.X = c->dX.as<double>();
@@ -1123,7 +1125,7 @@ struct Pipe {
     GPC_COV_DISPATCH(small_front_kernel, T, b.cd, dim3(3, cnt), dim3(256), 0, st, u, b.cd, hsp, hdvec, A, sM);
     hipLaunchKernelGGL((leaf_solve_kernel<T>), dim3(cnt), dim3(256), 0, st, A, sM, npad, W, sM, npad, d_logdet, d_info, N,
                        gpc::g_leaf_fault, rsrc, c->zvec.as<double>(), d_quad,
-                       mode == MODE_GRAD ? c->avec.as<double>() : nullptr, (const double*)c->spb.as<double>(),
+                       mode != MODE_NLL ? c->avec.as<double>() : nullptr, (const double*)c->spb.as<double>(),
                        (int)SP_STRIDE, (int)SP_SL, land, cnt);
     HIPCHK(c, hipGetLastError());
     c->last_flops += (2.0 / 3.0) * TILE * (double)TILE * TILE * cnt;
@@ -1267,7 +1269,7 @@ struct Pipe {
     }
     // Problems that are ONE 128 x 128 leaf take a pipeline of their own (small_section below); there the diagonal term
     // is read from its staged host copy by the build itself and needs no device copy
-    const bool small_ok = c->small_path && npad == TILE && mode != MODE_POST && !kmode() && !(stable || c->stable) &&
+    const bool small_ok = c->small_path && npad == TILE && !kmode() && !(stable || c->stable) &&
                           gpc::g_leaf_version == 5 && hsp && hmul && hdv;
     const void* hdvec = nullptr;
     if (small_ok)
@@ -1927,7 +1929,11 @@ int rhs_products(gpc_post* po, int mode, const double* xa, const double* xb, int
       g.lower_only = 0;
       g.A = (lch ? po->W.as<T>() : po->A.as<T>()) + (size_t)(s0 + a) * sM;  // V = W R | G = L R
       g.khi = lch ? KHI_ROW : KHI_FULL;
-      if (lch && !full) {
+      // (problems whose product is a handful of 128-tiles keep the 64-tile product + column-sum pass: latency regime.
+      // Decided by the problem size only, never by the number of samples: the two forms add in different orders, and a
+      // sample of a batch must carry the bits of its single evaluation)
+      const long long tiles128 = (long long)(npad / TILE) * (mpad / TILE);
+      if (lch && !full && tiles128 >= 64) {
         // the variance needs the column sums of squares of V only: the product's epilogue forms them per tile row and V
         // is never written (gemm.h: EPI = 1); a small reduction over the tile rows follows
         const int tm = npad / TILE;

@@ -218,7 +218,7 @@ struct Factor {
     // L21 back into A: only where L must survive as the Cholesky factor (posteriors).  The blocked forward solve
     // of an NLL-only evaluation reads L21 where it was computed, in the scratch (forward_solve below).
     if (keep_L) {
-      dim3 grid(n1 / 64, n2 / 4, batch), block(64, 4);
+      dim3 grid((n1 + 64 * MM<T>::VEC - 1) / (64 * MM<T>::VEC), n2 / 32, batch), block(64, 4);
       hipLaunchKernelGGL((rect_copy_kernel<T>), grid, block, 0, st, (const T*)blk(Tm, o2, o1), sT, npad,
                          blk(A, o2, o1), sA, npad, n2, n1);
       ++launches;

@@ -34,12 +34,13 @@ for k, v in sets.items():
                  f"{sorted(v - ref_set)}; only in stats_g1: {sorted(ref_set - v)} -- the passes are not of one code state")
 shutil.copy(stats, f"{P}/{tag}_kernel_stats_bench_cfg3.csv")
 shutil.copy(stats_g1, f"{P}/{tag}_kernel_stats_bench_cfg3_groups1.csv")
-shutil.copy(f"{O}/bench.json", f"{P}/{tag}_bench_cfg3.json")
+# (the tracked bench line is taken AFTER this script has written the traffic file, so that it quotes the PMC traffic of
+# its own code state: tools/evidence_r4.sh copies it)
 for line in open(f"{O}/prof_g1.log"):
-    if line.startswith('{"metric"'):
+    if line.startswith("{") and '"metric"' in line:
         open(f"{P}/{tag}_bench_cfg3_groups1_under_rocprof.json", "w").write(line)
         d = json.loads(line)
-        print("groups=1 under rocprof: dominant launch_ms", d["roofline"]["dominant_kernel"]["launch_ms"], "value", d["value"])
+        print("groups=1 under rocprof: dominant launch_ms", d["roofline"].get("launch_ms"), "value", d["value"])
 for r in csv.DictReader(open(f"{P}/{tag}_kernel_stats_bench_cfg3_groups1.csv")):
     if "true, true" in r["Name"]:
         print(r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e6, "ms avg", float(r["MinNs"]) / 1e6, float(r["MaxNs"]) / 1e6)
@@ -51,7 +52,7 @@ def load(t):
 
 out = open(f"{P}/{tag}_pmc_summary.txt", "w")
 out.write(f"code state (tools/source_hash.py): {source}\n")
-out.write("rocprofv3 --pmc passes on `bench.py --steps 1 --warmup 1` (cfg3, default 2 sample groups + 3 single-group steps for the dominant kernel);\n"
+out.write("rocprofv3 --pmc passes on `bench.py --steps 1 --warmup 1` (cfg3: 1 warm-up + 1 timed step + 3 untimed steps with the mat-vecs after the W^T W launch);\n"
           "counters summed per kernel name over the run; the last block lists the W^T W launch (gemm_persist_kernel<double,true,true,128,4>) per dispatch\n")
 per = {}
 for t in ("pmc1", "pmc2", "pmc3"):
@@ -66,7 +67,7 @@ for t in ("pmc1", "pmc2", "pmc3"):
     for n, c in sorted(acc.items()):
         out.write(f"{t} {n[:60]:60s} " + "  ".join(f"{k}={v:.4g}" for k, v in sorted(c.items())) + "\n")
     per[t] = disp
-out.write("\nper dispatch, W^T W launch (8-sample launches of the two groups, then the three 16-sample single-group launches):\n")
+out.write("\nper dispatch, W^T W launch (16 samples each; the last three with the mat-vecs after it instead of under it):\n")
 for t in per:
     for did, c in per[t].items():
         out.write(f"{t} dispatch {did}: " + "  ".join(f"{k}={v:.5g}" for k, v in sorted(c.items())) + "\n")
@@ -83,6 +84,27 @@ txt = (f"\nderived, 16-sample W^T W launch: MFMA busy {busy:.4g} cycles per SIMD
        f"L2 hit rate TCC_HIT/(TCC_HIT+TCC_MISS) = {100*hit/max(1.0,hit+miss):.0f}%.\n")
 out.write(txt)
 print(txt)
+# MFMA utilisation per GEMM class over the whole run: busy cycles / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), with the
+# kernel time of the class per step from the stats pass.  (A CU-reserving launch runs on 192 of 256 CUs by design and a
+# launch that shares the chip with another stream's kernels counts their time as its own: these are figures of the
+# class AS SCHEDULED, not of the kernel alone.)
+acc1 = collections.defaultdict(float)
+acc3 = collections.defaultdict(float)
+for r in load("pmc1"):
+    if r["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES":
+        acc1[r["Kernel_Name"].replace("void gpc::", "").split("(")[0]] += float(r["Counter_Value"])
+for r in load("pmc3"):
+    if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+        acc3[r["Kernel_Name"].replace("void gpc::", "").split("(")[0]] += float(r["Counter_Value"])
+ms = {}
+for r in csv.DictReader(open(f"{P}/{tag}_kernel_stats_bench_cfg3.csv")):
+    ms[r["Name"].replace("void gpc::", "").split("(")[0]] = float(r["TotalDurationNs"]) / 1e6 / 7.0  # 1 + 3 + 3 steps
+out.write("\nMFMA utilisation per GEMM class (busy / (GRBM_GUI_ACTIVE/8 x 1024)), kernel time of the class per cfg3 step:\n")
+for n in sorted(acc1):
+    if "gemm" in n and acc3.get(n, 0) > 0 and acc1[n] > 0:
+        line = f"  {n[:62]:62s} {100 * acc1[n] / (acc3[n] / 8 * 1024):5.1f} %   {ms.get(n, float('nan')):6.2f} ms per step"
+        out.write(line + "\n")
+        print(line)
 nsteps = 5
 tot_f = sum(float(r["Counter_Value"]) for r in load("pmc2") if r["Counter_Name"] == "FETCH_SIZE")
 tot_w = sum(float(r["Counter_Value"]) for r in load("pmc3") if r["Counter_Name"] == "WRITE_SIZE")
