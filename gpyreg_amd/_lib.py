@@ -21,9 +21,12 @@ F64, F32 = 0, 1
 KLO_ZERO, KLO_ROW, KLO_COL = 0, 1, 2
 KHI_FULL, KHI_ROW, KHI_COL = 0, 1, 2
 
-_dp = C.POINTER(C.c_double)
-_ip = C.POINTER(C.c_int)
+# Array arguments are declared void* and passed as the integer address of the NumPy buffer: `a.ctypes.data_as(POINTER(..))`
+# costs ~2 us per argument, the address ~1 us, and an evaluation has a dozen of them -- a visible share of a 90 us call.
+_dp = C.c_void_p  # double*
+_ip = C.c_void_p  # int*
 _vp = C.c_void_p
+_dpp = C.POINTER(C.c_double)  # typed, for the dK callback (its argument is wrapped as an array)
 
 # every symbol include/gpcore.h declares: (restype, argtypes)
 SIGNATURES = {
@@ -79,7 +82,7 @@ SIGNATURES = {
 }
 
 # int (*gpc_dk_plane_fn)(void* user, int sample, int p, double* plane)
-DK_PLANE_FN = C.CFUNCTYPE(C.c_int, _vp, C.c_int, C.c_int, _dp)
+DK_PLANE_FN = C.CFUNCTYPE(C.c_int, _vp, C.c_int, C.c_int, _dpp)
 
 _lib = None
 _lock = threading.RLock()
@@ -110,7 +113,7 @@ def _f64(a):
 
 
 def _ptr(a):
-    return None if a is None else a.ctypes.data_as(_dp)
+    return None if a is None else a.ctypes.data
 
 
 def _serial(method):
@@ -217,7 +220,7 @@ class Context:
         rc = self._lib.gpc_nll_batch(
             self._h, kid, degree, dtype, S, _ptr(hyp_cov), _ptr(m), _ptr(sn2), vec,
             1 if want_grad else 0, _ptr(dm_c), mean_N, _ptr(dsn2_c), noise_N, _ptr(nlz), _ptr(dnlz),
-            _ptr(mult), lchol.ctypes.data_as(_ip), info.ctypes.data_as(_ip))
+            _ptr(mult), lchol.ctypes.data, info.ctypes.data)
         self._check(rc, "gpc_nll_batch")
         return nlz, dnlz, mult, lchol.astype(bool), info
 
@@ -257,7 +260,7 @@ class Context:
         rc = self._lib.gpc_nll_batch_K(
             self._h, dtype, S, cov_N, _ptr(K), C.cast(cb, _vp) if want_grad else None, None, _ptr(m),
             _ptr(sn2), vec, 1 if want_grad else 0, _ptr(dm_c), mean_N, _ptr(dsn2_c), noise_N, _ptr(nlz),
-            _ptr(dnlz), _ptr(mult), lchol.ctypes.data_as(_ip), info.ctypes.data_as(_ip))
+            _ptr(dnlz), _ptr(mult), lchol.ctypes.data, info.ctypes.data)
         if err:
             raise err[0]
         self._check(rc, "gpc_nll_batch_K")
@@ -275,7 +278,7 @@ class Context:
         info = np.empty(S, dtype=np.int32)
         h = _vp()
         rc = self._lib.gpc_posterior_batch_K(self._h, dtype, S, _ptr(K), _ptr(m), _ptr(sn2), vec, C.byref(h),
-                                             _ptr(mult), lchol.ctypes.data_as(_ip), info.ctypes.data_as(_ip))
+                                             _ptr(mult), lchol.ctypes.data, info.ctypes.data)
         self._check(rc, "gpc_posterior_batch_K")
         return PostHandle(self, h, S, self.N), mult, lchol.astype(bool), info
 
@@ -294,7 +297,7 @@ class Context:
         h = _vp()
         rc = self._lib.gpc_posterior_batch(
             self._h, kid, degree, dtype, S, _ptr(hyp_cov), _ptr(m), _ptr(sn2), vec, C.byref(h),
-            _ptr(mult), lchol.ctypes.data_as(_ip), info.ctypes.data_as(_ip))
+            _ptr(mult), lchol.ctypes.data, info.ctypes.data)
         self._check(rc, "gpc_posterior_batch")
         return PostHandle(self, h, S, self.N), mult, lchol.astype(bool), info
 
@@ -402,7 +405,7 @@ class PostHandle:
         m_star, sn2_star = _f64(m_star).ravel(), _f64(sn2_star).ravel()
         ok = np.zeros(self.S, dtype=np.int32)
         rc = self.ctx._lib.gpc_post_append(self._h, _ptr(m_star), _ptr(sn2_star), float(y_new),
-                                           ok.ctypes.data_as(_ip))
+                                           ok.ctypes.data)
         self.ctx._check(rc, "gpc_post_append")
         self.N += 1
         return ok.astype(bool)
@@ -417,7 +420,7 @@ class PostHandle:
             raise ValueError("Ks must be (S, n) and kss (S,)")
         ok = np.zeros(self.S, dtype=np.int32)
         rc = self.ctx._lib.gpc_post_append_K(self._h, _ptr(Ks), _ptr(kss), _ptr(m_star), _ptr(sn2_star),
-                                             float(y_new), ok.ctypes.data_as(_ip))
+                                             float(y_new), ok.ctypes.data)
         self.ctx._check(rc, "gpc_post_append_K")
         self.N += 1
         return ok.astype(bool)
@@ -435,14 +438,14 @@ class PostHandle:
         if K is not None:
             K = _f64(K)
             rc = self.ctx._lib.gpc_post_recompute_K(
-                self._h, cnt, idx.ctypes.data_as(_ip), _ptr(K), _ptr(m), _ptr(sn2),
-                1 if sn2_is_vector else 0, _ptr(mult), lchol.ctypes.data_as(_ip), info.ctypes.data_as(_ip))
+                self._h, cnt, idx.ctypes.data, _ptr(K), _ptr(m), _ptr(sn2),
+                1 if sn2_is_vector else 0, _ptr(mult), lchol.ctypes.data, info.ctypes.data)
             self.ctx._check(rc, "gpc_post_recompute_K")
             return mult, lchol.astype(bool), info
         hyp_cov = _f64(hyp_cov)
         rc = self.ctx._lib.gpc_post_recompute(
-            self._h, cnt, idx.ctypes.data_as(_ip), _ptr(hyp_cov), _ptr(m), _ptr(sn2),
-            1 if sn2_is_vector else 0, _ptr(mult), lchol.ctypes.data_as(_ip), info.ctypes.data_as(_ip))
+            self._h, cnt, idx.ctypes.data, _ptr(hyp_cov), _ptr(m), _ptr(sn2),
+            1 if sn2_is_vector else 0, _ptr(mult), lchol.ctypes.data, info.ctypes.data)
         self.ctx._check(rc, "gpc_post_recompute")
         return mult, lchol.astype(bool), info
 

@@ -92,3 +92,38 @@ def test_predict_mode_reports_a_roofline_and_matches_the_oracle():
     assert line["unit"] == "point-samples/s" and line["value"] > 0
     assert line["roofline"]["launch_ms"] > 0 and 0 < line["roofline"]["frac"] < 1
     assert line["cpu_baseline"]["mu_abs_err"] < 1e-8 and line["cpu_baseline"]["s2_rel_err"] < 1e-6
+
+
+@pytest.mark.gpu
+def test_the_rccl_branch_with_one_rank():
+    """One GPU cannot hold two nccl ranks, but the code the 8-GPU run goes through -- `init_process_group("nccl")`, device
+    tensors in `sharding._Gather`, `all_gather_into_tensor` / `all_gather_object` / `all_reduce` on the device, the
+    barrier before the group is destroyed -- runs with a group of ONE rank too: the bench under BENCH_FORCE_DIST, and the
+    gather on device tensors directly."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+           "BENCH_FORCE_DIST": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    r, line = _bench("--gpus", "1", "--config", "2", "--samples", "3", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                     env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert line["n_gpus"] == 1 and line["config"]["backend"].startswith("nccl") and line["value"] > 0
+    code = (
+        "import os, sys, numpy as np, torch, torch.distributed as dist\n"
+        "sys.path.insert(0, %r)\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', device_id=torch.device('cuda', 0))\n"
+        "from gpyreg_amd import sharding as sh\n"
+        "a = np.arange(12.0).reshape(4, 3)\n"
+        "g = sh._Gather(a, 4)\n"
+        "assert g.out.is_cuda and np.array_equal(g.result(), a)\n"
+        "dist.barrier(); dist.destroy_process_group(); print('gather ok')\n" % ROOT)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    e = dict(os.environ, **env, MASTER_PORT=str(port))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=e, cwd=ROOT)
+    assert p.returncode == 0 and "gather ok" in p.stdout, p.stderr[-3000:]

@@ -1,4 +1,4 @@
-"""Copies the evidence of a tools/gpu_run.sh run (gpurun_out/<run>) into profiles/ under a round tag and
+"""Copies the evidence of a tools/evidence_a.sh run (gpurun_out/<run>) into profiles/ under a round tag and
 derives the PMC summary (MFMA utilisation, clock, memory-side traffic).  usage: assemble_profiles.py <run> <tag>"""
 import collections, csv, glob, json, shutil, sys
 
@@ -35,7 +35,7 @@ for k, v in sets.items():
 shutil.copy(stats, f"{P}/{tag}_kernel_stats_bench_cfg3.csv")
 shutil.copy(stats_g1, f"{P}/{tag}_kernel_stats_bench_cfg3_groups1.csv")
 # (the tracked bench line is taken AFTER this script has written the traffic file, so that it quotes the PMC traffic of
-# its own code state: tools/evidence_r4.sh copies it)
+# its own code state: tools/evidence_a.sh copies it)
 for line in open(f"{O}/prof_g1.log"):
     if line.startswith("{") and '"metric"' in line:
         open(f"{P}/{tag}_bench_cfg3_groups1_under_rocprof.json", "w").write(line)

@@ -1,10 +1,10 @@
 #!/bin/bash
-# Round-4 evidence, part A (GPU box, repo root):  bash tools/evidence_r4.sh <run-tag> <profiles-tag>
+# Round-4 evidence, part A (GPU box, repo root):  bash tools/evidence_a.sh <run-tag> <profiles-tag>
 #   GPU tests -> smoke -> rocprofv3 kernel stats + the three PMC passes of the cfg3 bench -> profiles/<ptag>_* assembled ON
 #   THE BOX (so that the traffic file exists before the tracked line is taken) -> the tracked bench line (it then quotes
 #   the PMC traffic of its own code state).  Everything lands under gpurun_out/<run-tag>/ (profiles/ in its subdirectory).
 set -o pipefail
-TAG=${1:?usage: evidence_r4.sh <run-tag> <profiles-tag>}; PTAG=${2:?profiles tag}
+TAG=${1:?usage: evidence_a.sh <run-tag> <profiles-tag>}; PTAG=${2:?profiles tag}
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/$TAG
 rm -rf "$O"; mkdir -p "$O/profiles"; cd $R
 python3 tools/source_hash.py > $O/source.sha256

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round-4 evidence, part B: the other configurations and modes.  bash tools/evidence_r4b.sh <run-tag> <profiles-tag>
+# Round-4 evidence, part B: the other configurations and modes.  bash tools/evidence_b.sh <run-tag> <profiles-tag>
 set -o pipefail
-TAG=${1:?usage: evidence_r4b.sh <run-tag> <profiles-tag>}; PTAG=${2:?profiles tag}
+TAG=${1:?usage: evidence_b.sh <run-tag> <profiles-tag>}; PTAG=${2:?profiles tag}
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/$TAG
 rm -rf "$O"; mkdir -p "$O/profiles"; cd $R
 python3 tools/source_hash.py > $O/source.sha256
