@@ -146,8 +146,8 @@ __global__ __launch_bounds__(256) void xfer_kernel(XferDesc d) {
 // device copies are being written by other blocks of this very launch and are not ordered against this read).
 template <typename T, int KIND, int DEG>
 __global__ __launch_bounds__(256) void small_front_kernel(XferDesc d, CovDesc cd, const double* __restrict__ sp_h,
-                                                          const double* __restrict__ dvec_h, T* __restrict__ A_all,
-                                                          long long sA) {
+                                                          const double* __restrict__ dvec_h, int dvec_vec,
+                                                          T* __restrict__ A_all, long long sA) {
   __shared__ double xi[CT][DCH + 1];
   __shared__ double xj[CT][DCH + 1];
   // this sample's host-resident inputs, fetched ONCE: a load from mapped host memory is a PCIe round trip (~2.5 us),
@@ -164,7 +164,8 @@ __global__ __launch_bounds__(256) void small_front_kernel(XferDesc d, CovDesc cd
   // the diagonal term is read by the diagonal tiles only (tile 0: rows 0..63, tile 2: rows 64..127)
   const int drow = blockIdx.x == 2 ? CT : 0;
   const bool dg = blockIdx.x != 1 && t < CT;
-  if (dg) v0 = dvec_h[(size_t)b * TILE + drow + t];
+  // (dvec_vec = 0: one value per sample -- scalar noise; the padding rows carry 1 either way)
+  if (dg) v0 = dvec_vec ? dvec_h[(size_t)b * TILE + drow + t] : (drow + t < d.n ? dvec_h[b] : 1.0);
   if (t < SP_STRIDE) v1 = sp_h[(size_t)b * SP_STRIDE + t];
   if (dl && t < d.D) {
     v2 = d.mul[(size_t)b * d.D + t];
@@ -1122,7 +1123,8 @@ struct Pipe {
     u.D = D;
     u.cnt = cnt;
     HIPCHK(c, hipEventRecord(c->ev[1], st));
-    GPC_COV_DISPATCH(small_front_kernel, T, b.cd, dim3(3, cnt), dim3(256), 0, st, u, b.cd, hsp, hdvec, A, sM);
+    GPC_COV_DISPATCH(small_front_kernel, T, b.cd, dim3(3, cnt), dim3(256), 0, st, u, b.cd, hsp, hdvec, b.vec_noise ? 1 : 0,
+                     A, sM);
     hipLaunchKernelGGL((leaf_solve_kernel<T>), dim3(cnt), dim3(256), 0, st, A, sM, npad, W, sM, npad, d_logdet, d_info, N,
                        gpc::g_leaf_fault, rsrc, c->zvec.as<double>(), d_quad,
                        mode != MODE_NLL ? c->avec.as<double>() : nullptr, (const double*)c->spb.as<double>(),
@@ -1272,11 +1274,17 @@ struct Pipe {
     const bool small_ok = c->small_path && npad == TILE && !kmode() && !(stable || c->stable) &&
                           gpc::g_leaf_version == 5 && hsp && hmul && hdv;
     const void* hdvec = nullptr;
-    if (small_ok)
-      if (void* h = c->pin.alloc(cnt * vb)) {
-        memcpy(h, &b.dvec[(size_t)s0 * npad], cnt * vb);
+    if (small_ok) {
+      if (b.vec_noise) {
+        if (void* h = c->pin.alloc(cnt * vb)) {
+          memcpy(h, &b.dvec[(size_t)s0 * npad], cnt * vb);
+          hdvec = h;
+        }
+      } else if (void* h = c->pin.alloc((size_t)cnt * 8)) {  // scalar noise: the diagonal term is one value per sample
+        for (int i = 0; i < cnt; ++i) static_cast<double*>(h)[i] = b.dvec[(size_t)(s0 + i) * npad];
         hdvec = h;
       }
+    }
     if (!hdvec) up(c->dvec.p, &b.dvec[(size_t)s0 * npad], cnt * vb);
     // ... and r = y - m is read from its staged copy by the kernel that needs it (leaf_solve_kernel, at its start:
     // the round trip to host memory hides under the factorization)

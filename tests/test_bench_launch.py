@@ -124,6 +124,6 @@ def test_the_rccl_branch_with_one_rank():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    e = dict(os.environ, **env, MASTER_PORT=str(port))
+    e = dict(os.environ, **dict(env, MASTER_PORT=str(port)))
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=e, cwd=ROOT)
     assert p.returncode == 0 and "gather ok" in p.stdout, p.stderr[-3000:]
