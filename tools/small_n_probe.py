@@ -14,7 +14,6 @@ def timeit(f, reps):
         f()
     return (time.perf_counter() - t0) / reps
 
-rows = []
 for N, S in [(50, 1), (100, 1), (128, 1), (200, 1), (256, 1), (50, 1024), (100, 1024), (128, 1024), (200, 1024), (256, 1024), (500, 1024)]:
     bench.CONFIGS[2] = dict(bench.CONFIGS[2], N=N)
     X, y, hyp = bench.synthetic_problem(2, S)

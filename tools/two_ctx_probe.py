@@ -16,7 +16,6 @@ for K in (2, 4, 8):
     gp.update(X_new=X, y_new=y, hyp=hyp[:1], compute_posterior=False)
     kid, deg = gp._kid()
     cov_N = gp._counts()[0]
-    ctx0 = _lib.context()
     for _ in range(3):
         gp.nll_batch(hyp, grad)
     t0 = time.perf_counter()
