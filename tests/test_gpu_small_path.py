@@ -137,3 +137,33 @@ def test_a_leaf_time_out_in_the_small_pipeline_is_an_error(ctx):
         ctx.set_option("leaf_fault", 0)
     n, _ = gp.nll_batch(hyp, compute_grad=False)
     assert np.isfinite(n).all()
+
+
+def test_fused_predict_product_in_fp32_against_fp64():
+    """The predict product whose epilogue forms the variance sums (gemm.h: EPI = 1) with the fp32 two-level accumulators:
+    N = 1500, M = 700 (12 x 6 tiles: the fused form), fp32 mode against fp64 mode at north_star's 1e-3, and fp64 against
+    the CPU oracle."""
+    import gpyreg_amd as gpr
+    from oracle import gp_oracle as orc  # checker only
+
+    N, D, S, M = 1500, 4, 3, 700
+    rng, X, y = _problem(N, D, 77)
+    hyp = np.concatenate([np.log(1.5) * np.ones(D), [0.0, np.log(0.2), 0.1]]) + 0.1 * rng.standard_normal((S, D + 3))
+    xs = rng.uniform(-3, 3, (M, D))
+    res = {}
+    for dtype in ("f64", "f32"):
+        gp = gpr.GP(D, gpr.covariance_functions.Matern(5), gpr.mean_functions.ConstantMean(),
+                    gpr.noise_functions.GaussianNoise(constant_add=True), dtype=dtype)
+        gp.update(X_new=X, y_new=y, hyp=hyp)
+        res[dtype] = gp.predict(xs, separate_samples=True)
+        one = gpr.GP(D, gpr.covariance_functions.Matern(5), gpr.mean_functions.ConstantMean(),
+                     gpr.noise_functions.GaussianNoise(constant_add=True), dtype=dtype)
+        one.update(X_new=X, y_new=y, hyp=hyp[1:2])
+        m1, v1 = one.predict(xs, separate_samples=True)
+        assert np.array_equal(m1[:, 0], res[dtype][0][:, 1]) and np.array_equal(v1[:, 0], res[dtype][1][:, 1])
+    model = dict(kernel="matern", degree=5, mean="const", noise=(1, 0, 0))
+    posts = orc.posteriors(model, hyp, X, y, None)
+    rmu, rs2 = orc.predict(model, posts, X, y, xs, separate_samples=True)
+    assert np.abs(res["f64"][0] - rmu).max() < 1e-8 and np.abs(res["f64"][1] - rs2).max() < 1e-8 * max(1.0, rs2.max())
+    assert np.abs(res["f32"][0] - rmu).max() < 1e-3 * max(1.0, np.abs(rmu).max())
+    assert np.abs(res["f32"][1] - rs2).max() < 1e-3 * max(1.0, rs2.max())
