@@ -114,6 +114,29 @@ def test_cfg5_last_sample_of_64_against_the_reference(ctx):
     assert _rel_grad(d[0], g["cfg5_dnlZ"][list(g["cfg5_rows_with_grad"]).index(63)]) < 1e-8
 
 
+def test_cfg5_full_batch_of_64_against_the_reference(ctx):
+    """cfg5 exactly as BASELINE.json states it -- N = 8192, D = 8, SE, the FULL batch of 64 hyperparameter samples in one
+    call (103 GB of factor workspace, two sample groups) -- against every value the reference computed for that sequence
+    (samples 0, 7, 8, 63; gradients of 0 and 63), and its last row against its single evaluation bit for bit."""
+    import bench
+
+    g = np.load(GOLD, allow_pickle=False)
+    X, y, hyp = bench.synthetic_problem(5, 64)
+    gp = bench.make_gp(5, "f64")
+    gp.update(X_new=X, y_new=y, hyp=hyp[:1], compute_posterior=False)
+    nlz, dnlz = gp.nll_batch(hyp, compute_grad=True)
+    assert nlz.shape == (64,) and np.isfinite(nlz).all() and np.isfinite(dnlz).all()
+    with_grad = [int(r) for r in g["cfg5_rows_with_grad"]]
+    for k, s in enumerate(g["cfg5_rows"]):
+        assert np.array_equal(hyp[s], g["cfg5_hyp"][k])
+        rn = g["cfg5_nlZ"][k]
+        assert abs(nlz[s] - rn) < 1e-8 * max(1.0, abs(rn)), (s, nlz[s], rn)
+        if int(s) in with_grad:
+            assert _rel_grad(dnlz[s], g["cfg5_dnlZ"][with_grad.index(int(s))]) < 1e-8, s
+    n1, d1 = gp.nll_batch(hyp[63:64], compute_grad=True)
+    assert n1[0] == nlz[63] and np.array_equal(d1[0], dnlz[63])
+
+
 def test_cfg4_against_the_reference_fp64_and_fp32(ctx):
     """cfg4, N = 16384, D = 20, rational quadratic.  The reference's value exists for the NLL only (its gradient
     tensor would be 47 GB): fp64 device NLL within 1e-8 of it, fp32 within 1e-3 (north_star); the fp32 gradient is
