@@ -127,3 +127,25 @@ def test_the_rccl_branch_with_one_rank():
     e = dict(os.environ, **dict(env, MASTER_PORT=str(port)))
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=e, cwd=ROOT)
     assert p.returncode == 0 and "gather ok" in p.stdout, p.stderr[-3000:]
+
+
+def test_under_torch_distributed_run_exactly_as_the_driver_launches_it():
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+    --gpus N ...` (the multi-GPU command of the bench contract), here with --dry-run: no second launch of ranks, the
+    launcher's environment is used, rank 0 prints the one line."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--dry-run", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=e, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["launcher"] in ("torchrun", "env")
+    assert line["config"]["global_samples"] == 16 and line["config"]["samples_per_gpu"] == 8
