@@ -46,6 +46,11 @@ SIGNATURES = {
         [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, C.c_int, _dp, C.c_int,
          _dp, C.c_int, _dp, _dp, _dp, _ip, _ip],
     ),
+    "gpc_nll_batch_cm": (
+        C.c_int,
+        [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int, _dp, C.c_int, C.c_int, _dp, C.c_int,
+         _dp, _dp, _dp, _ip, _ip],
+    ),
     "gpc_posterior_batch": (
         C.c_int,
         [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, C.POINTER(_vp), _dp, _ip, _ip],
@@ -222,6 +227,33 @@ class Context:
             1 if want_grad else 0, _ptr(dm_c), mean_N, _ptr(dsn2_c), noise_N, _ptr(nlz), _ptr(dnlz),
             _ptr(mult), lchol.ctypes.data, info.ctypes.data)
         self._check(rc, "gpc_nll_batch")
+        return nlz, dnlz, mult, lchol.astype(bool), info
+
+    @_serial
+    def nll_batch_cm(self, kid, degree, dtype, hyp_cov, m0, sn2, sn2_is_vector, want_grad=False, dsn2=None):
+        """gpc_nll_batch_cm: the stock zero / constant mean as ONE value per sample -- m0 (S,) or None for the zero
+        mean; dsn2 (S, N if sn2_is_vector else 1, noise_N).  Same results as ``nll_batch`` with m = m0 and dm = 1."""
+        hyp_cov = _f64(hyp_cov)
+        sn2 = _f64(sn2)
+        S, cov_N = hyp_cov.shape
+        vec = 1 if sn2_is_vector else 0
+        mean_N = 0 if m0 is None else 1
+        m0_c = None if m0 is None else _f64(m0).ravel()
+        if sn2.shape != (S, self.N if vec else 1) or (m0_c is not None and m0_c.shape != (S,)):
+            raise ValueError("m0 must be (S,); sn2 must be (S,N) when per-point, else (S,1)")
+        noise_N = 0 if dsn2 is None else dsn2.shape[2]
+        dsn2_c = None if dsn2 is None or noise_N == 0 else _f64(dsn2)
+        hyp_N = cov_N + noise_N + mean_N
+        nlz = np.empty(S)
+        dnlz = np.empty((S, hyp_N)) if want_grad else None
+        mult = np.empty(S)
+        lchol = np.empty(S, dtype=np.int32)
+        info = np.empty(S, dtype=np.int32)
+        rc = self._lib.gpc_nll_batch_cm(
+            self._h, kid, degree, dtype, S, _ptr(hyp_cov), _ptr(m0_c), mean_N, _ptr(sn2), vec,
+            1 if want_grad else 0, _ptr(dsn2_c), noise_N, _ptr(nlz), _ptr(dnlz), _ptr(mult), lchol.ctypes.data,
+            info.ctypes.data)
+        self._check(rc, "gpc_nll_batch_cm")
         return nlz, dnlz, mult, lchol.astype(bool), info
 
     @_serial

@@ -254,7 +254,9 @@ __global__ __launch_bounds__(256) void grad_tail_kernel(const double* __restrict
     out = gout + (size_t)b * P + x;
   } else if (x < P + mean_N) {
     const int p = x - P;
-    for (int i = threadIdx.x; i < n; i += 256) s += dm[((size_t)b * n + i) * mean_N + p] * alpha[(size_t)b * vstride + i];
+    // (dm == nullptr: the derivative of a constant mean, all ones)
+    for (int i = threadIdx.x; i < n; i += 256)
+      s += (dm ? dm[((size_t)b * n + i) * mean_N + p] : 1.0) * alpha[(size_t)b * vstride + i];
     out = mg + (size_t)b * mean_N + p;
   } else {
     const int p = x - P - mean_N;

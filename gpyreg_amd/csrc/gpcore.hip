@@ -98,6 +98,15 @@ struct XferDesc {
   const double* dv = nullptr;
   double* xs = nullptr;
   int n = 0, npad = 0, D = 0, cnt = 0;
+  // optional (gpc_nll_batch_cm: constant mean, and / or scalar noise): what the host would otherwise compute per point
+  // and upload -- r[b][i] = y[i] - m0[b] from the RESIDENT y and the per-sample constant, dvec[b][i] = dval[b] (1 in
+  // the identity padding) -- formed here; m0 / dval are staged host copies (one value per sample)
+  const double* y = nullptr;
+  const double* m0 = nullptr;
+  double* r_out = nullptr;
+  const double* dval = nullptr;
+  double* dvec_out = nullptr;
+  int fn = 0, fnpad = 0, fcnt = 0;
 };
 __device__ __forceinline__ void xfer_body_noxs(const XferDesc& d, unsigned long long gt, unsigned long long stride) {
   // the segments as ONE index space: a thread's words are independent loads from (mapped) host memory, all in flight
@@ -120,6 +129,15 @@ __device__ __forceinline__ void xfer_body_noxs(const XferDesc& d, unsigned long 
   }
   unsigned long long* z = reinterpret_cast<unsigned long long*>(d.zero);
   for (unsigned long long i = gt; i < d.zero8; i += stride) z[i] = 0ull;
+  if (d.r_out || d.dvec_out) {
+    const unsigned long long tot = (unsigned long long)d.fnpad * d.fcnt;
+    for (unsigned long long q = gt; q < tot; q += stride) {
+      const unsigned long long b = q / d.fnpad;
+      const int i = (int)(q - b * d.fnpad);
+      if (d.r_out) d.r_out[q] = i < d.fn ? d.y[i] - d.m0[b] : 0.0;
+      if (d.dvec_out) d.dvec_out[q] = i < d.fn ? d.dval[b] : 1.0;
+    }
+  }
 }
 __device__ __forceinline__ void xfer_body(const XferDesc& d, unsigned long long gt, unsigned long long stride) {
   xfer_body_noxs(d, gt, stride);
@@ -283,6 +301,7 @@ struct PinBuf {
   void begin_gather() {
     upd.nseg = downd.nseg = 0;
     upd.xs = nullptr;
+    upd.r_out = upd.dvec_out = nullptr;
     upd.zero = downd.zero = nullptr;
     upd.zero8 = downd.zero8 = 0;
     up_fallback.clear();
@@ -315,8 +334,9 @@ struct PinBuf {
     }
     upd.zero = zero;
     upd.zero8 = zero_bytes / 8;
-    if (upd.nseg == 0 && upd.zero8 == 0 && !upd.xs) return hipSuccess;
-    const unsigned long long words = gathered_bytes / 8 + upd.zero8 + (upd.xs ? (unsigned long long)upd.npad * upd.D * upd.cnt : 0ull);
+    if (upd.nseg == 0 && upd.zero8 == 0 && !upd.xs && !upd.r_out && !upd.dvec_out) return hipSuccess;
+    const unsigned long long words = gathered_bytes / 8 + upd.zero8 + (upd.xs ? (unsigned long long)upd.npad * upd.D * upd.cnt : 0ull) +
+                                     ((upd.r_out || upd.dvec_out) ? (unsigned long long)upd.fnpad * upd.fcnt : 0ull);
     const int blocks = (int)std::min<unsigned long long>(256, (words + 255) / 256);
     hipLaunchKernelGGL(xfer_kernel, dim3(std::max(1, blocks)), dim3(256), 0, st, upd);
     upd.nseg = 0;
@@ -416,6 +436,7 @@ struct gpc_ctx {
   // resident training data
   int N = 0, D = 0, npad = 0;
   DevBuf dX;  // N x D
+  DevBuf dY;  // N (gpc_nll_batch_cm forms r = y - m0 on the device)
   std::vector<double> hy;
   // workspace
   DevBuf mA, mW, mT;             // matrices of the current chunk
@@ -649,6 +670,7 @@ struct Batch {
   int S = 0, N = 0, D = 0, npad = 0;
   CovDesc cd{};
   bool vec_noise = false;
+  bool m_const = false;  // m holds ONE value per sample (constant / zero mean: gpc_nll_batch_cm); r is formed on the device
   const double* hyp_cov = nullptr;
   const double* m = nullptr;
   const double* sn2 = nullptr;
@@ -663,7 +685,7 @@ struct Batch {
     dv.assign((size_t)S * D, 1.0);
     sp.assign((size_t)S * SP_STRIDE, 0.0);
     dvec.assign((size_t)S * npad, 1.0);
-    r.assign((size_t)S * npad, 0.0);
+    if (!m_const) r.assign((size_t)S * npad, 0.0);
     smin.assign(S, 0.0);
     mult.assign(S, mult0);
     sl.assign(S, 1.0);
@@ -683,7 +705,8 @@ struct Batch {
         for (int i = 1; i < N; ++i) mn = std::min(mn, sn[i]);
       smin[s] = mn;
       lchol[s] = (mn >= 1e-6) ? 1 : 0;  // gaussian_process.py:2404
-      for (int i = 0; i < N; ++i) r[(size_t)s * npad + i] = y[i] - m[(size_t)s * N + i];
+      if (!m_const)
+        for (int i = 0; i < N; ++i) r[(size_t)s * npad + i] = y[i] - m[(size_t)s * N + i];
       apply_mult(s);
     }
   }
@@ -978,7 +1001,7 @@ struct Pipe {
         const int mN = mean_N > 0 ? mean_N : 0, nN = (noise_N > 0 && b.vec_noise) ? noise_N : 0;
         hipLaunchKernelGGL(grad_tail_kernel, dim3(Pn + mN + nN, n), dim3(256), 0, st, (const double*)parts, ntl, Pn,
                            c->gout.as<double>() + (size_t)off * Pn,
-                           mN ? (const double*)(c->dmb.as<double>() + (size_t)off * N * mean_N) : nullptr, N, mN,
+                           (mN && dm) ? (const double*)(c->dmb.as<double>() + (size_t)off * N * mean_N) : nullptr, N, mN,
                            (const double*)avec, mN ? c->mg.as<double>() + (size_t)off * mean_N : nullptr,
                            nN ? (const double*)(c->dsn2b.as<double>() + (size_t)off * N * noise_N) : nullptr, nN,
                            (const double*)diagq, nN ? c->ng.as<double>() + (size_t)off * noise_N : nullptr, npad);
@@ -1152,7 +1175,7 @@ struct Pipe {
                        (const double*)c->avec.as<double>(), N, npad, (const T*)Tm, sM, npad, parts, ntl, diagq);
       const int mN = mean_N > 0 ? mean_N : 0, nN = (noise_N > 0 && b.vec_noise) ? noise_N : 0;
       hipLaunchKernelGGL(grad_tail_kernel, dim3(Pn + mN + nN, cnt), dim3(256), 0, st, (const double*)parts, ntl, Pn,
-                         c->gout.as<double>(), mN ? (const double*)c->dmb.as<double>() : nullptr, N, mN,
+                         c->gout.as<double>(), (mN && dm) ? (const double*)c->dmb.as<double>() : nullptr, N, mN,
                          (const double*)c->avec.as<double>(), mN ? c->mg.as<double>() : nullptr,
                          nN ? (const double*)c->dsn2b.as<double>() : nullptr, nN, (const double*)diagq,
                          nN ? c->ng.as<double>() : nullptr, npad);
@@ -1239,7 +1262,7 @@ struct Pipe {
       HIPCHK(c, c->gout.ensure((size_t)cnt * Pn * sizeof(double)));
       HIPCHK(c, c->diagq.ensure(cnt * vb));
       if (mean_N > 0) {
-        HIPCHK(c, c->dmb.ensure((size_t)cnt * N * mean_N * 8));
+        if (dm) HIPCHK(c, c->dmb.ensure((size_t)cnt * N * mean_N * 8));
         HIPCHK(c, c->mg.ensure((size_t)cnt * mean_N * 8));
       }
       if (noise_N > 0 && b.vec_noise) {
@@ -1273,29 +1296,57 @@ struct Pipe {
     // is read from its staged host copy by the build itself and needs no device copy
     const bool small_ok = c->small_path && npad == TILE && !kmode() && !(stable || c->stable) &&
                           gpc::g_leaf_version == 5 && hsp && hmul && hdv;
+    // The diagonal term and r = y - m.  Scalar noise / a constant mean (gpc_nll_batch_cm) are ONE value per sample:
+    // they are staged as such and expanded on the device by the upload kernel (no S x N arrays cross the bus).
     const void* hdvec = nullptr;
-    if (small_ok) {
-      if (b.vec_noise) {
-        if (void* h = c->pin.alloc(cnt * vb)) {
-          memcpy(h, &b.dvec[(size_t)s0 * npad], cnt * vb);
-          hdvec = h;
-        }
-      } else if (void* h = c->pin.alloc((size_t)cnt * 8)) {  // scalar noise: the diagonal term is one value per sample
+    const void* hr = nullptr;
+    bool fill_dvec = false, fill_r = false;
+    XferDesc& fu = c->pin.upd;
+    if (!b.vec_noise && !kmode()) {
+      if (void* h = c->pin.alloc((size_t)cnt * 8)) {
         for (int i = 0; i < cnt; ++i) static_cast<double*>(h)[i] = b.dvec[(size_t)(s0 + i) * npad];
+        if (small_ok) {
+          hdvec = h;  // read by the build of the one-leaf pipeline directly
+        } else {
+          fu.dval = static_cast<const double*>(h);
+          fu.dvec_out = c->dvec.as<double>();
+          fill_dvec = true;
+        }
+      }
+    } else if (small_ok) {
+      if (void* h = c->pin.alloc(cnt * vb)) {
+        memcpy(h, &b.dvec[(size_t)s0 * npad], cnt * vb);
         hdvec = h;
       }
     }
-    if (!hdvec) up(c->dvec.p, &b.dvec[(size_t)s0 * npad], cnt * vb);
-    // ... and r = y - m is read from its staged copy by the kernel that needs it (leaf_solve_kernel, at its start:
-    // the round trip to host memory hides under the factorization)
-    const void* hr = nullptr;
-    if (hdvec)
-      if (void* h = c->pin.alloc(cnt * vb)) {
-        memcpy(h, &b.r[(size_t)s0 * npad], cnt * vb);
-        hr = h;
+    if (!hdvec && !fill_dvec) up(c->dvec.p, &b.dvec[(size_t)s0 * npad], cnt * vb);
+    if (b.m_const) {
+      if (void* h = c->pin.alloc((size_t)cnt * 8)) {
+        memcpy(h, b.m + s0, (size_t)cnt * 8);
+        fu.y = c->dY.as<double>();
+        fu.m0 = static_cast<const double*>(h);
+        fu.r_out = c->rvec.as<double>();
+        fill_r = true;
+      } else {
+        FAIL(c, "out of pinned host memory");
       }
-    if (!hr) up(c->rvec.p, &b.r[(size_t)s0 * npad], cnt * vb);
-    if (mode == MODE_GRAD && mean_N > 0) up(c->dmb.p, dm + (size_t)s0 * N * mean_N, (size_t)cnt * N * mean_N * 8);
+    } else {
+      // r = y - m is read from its staged copy by the kernel that needs it (leaf_solve_kernel, at its start: the round
+      // trip to host memory hides under the factorization)
+      if (small_ok && hdvec)
+        if (void* h = c->pin.alloc(cnt * vb)) {
+          memcpy(h, &b.r[(size_t)s0 * npad], cnt * vb);
+          hr = h;
+        }
+      if (!hr) up(c->rvec.p, &b.r[(size_t)s0 * npad], cnt * vb);
+    }
+    if (fill_dvec || fill_r) {
+      fu.fn = N;
+      fu.fnpad = npad;
+      fu.fcnt = cnt;
+    }
+    // (dm == nullptr with mean_N = 1: the constant mean's derivative, all ones -- nothing to upload)
+    if (mode == MODE_GRAD && mean_N > 0 && dm) up(c->dmb.p, dm + (size_t)s0 * N * mean_N, (size_t)cnt * N * mean_N * 8);
     if (mode == MODE_GRAD && noise_N > 0 && b.vec_noise)
       up(c->dsn2b.p, dsn2 + (size_t)s0 * N * noise_N, (size_t)cnt * N * noise_N * 8);
     // Problems that are ONE 128 x 128 leaf (N <= 128; decided by the problem size only, so that a row of a batch carries
@@ -1457,14 +1508,18 @@ struct Pipe {
       sb.cd = b.cd;
       sb.vec_noise = b.vec_noise;
       sb.y = b.y;
-      std::vector<double> hc(b.hyp_cov ? (size_t)nf * cov_N : 0), mm((size_t)nf * N), sn((size_t)nf * nsn), gdm, gds;
-      const bool gm = mode == MODE_GRAD && mean_N > 0, gn = mode == MODE_GRAD && noise_N > 0 && b.vec_noise;
+      std::vector<double> hc(b.hyp_cov ? (size_t)nf * cov_N : 0), mm((size_t)nf * (b.m_const ? 1 : N)), sn((size_t)nf * nsn), gdm, gds;
+      const bool gm = mode == MODE_GRAD && mean_N > 0 && dm, gn = mode == MODE_GRAD && noise_N > 0 && b.vec_noise;
+      sb.m_const = b.m_const;
       if (gm) gdm.resize((size_t)nf * N * mean_N);
       if (gn) gds.resize((size_t)nf * N * noise_N);
       for (int i = 0; i < nf; ++i) {
         const int s = fail[i];
         if (b.hyp_cov) std::copy_n(b.hyp_cov + (size_t)s * cov_N, cov_N, &hc[(size_t)i * cov_N]);
-        std::copy_n(b.m + (size_t)s * N, N, &mm[(size_t)i * N]);
+        if (b.m_const)
+          mm[i] = b.m[s];
+        else
+          std::copy_n(b.m + (size_t)s * N, N, &mm[(size_t)i * N]);
         std::copy_n(b.sn2 + (size_t)s * nsn, nsn, &sn[(size_t)i * nsn]);
         if (gm) std::copy_n(dm + (size_t)s * N * mean_N, (size_t)N * mean_N, &gdm[(size_t)i * N * mean_N]);
         if (gn) std::copy_n(dsn2 + (size_t)s * N * noise_N, (size_t)N * noise_N, &gds[(size_t)i * N * noise_N]);
@@ -1649,7 +1704,8 @@ int check_batch_args(gpc_ctx* c, int kernel_id, int degree, int dtype, int S) {
 }
 
 void fill_batch(gpc_ctx* c, Batch& b, int kernel_id, int degree, int S, const double* hyp_cov,
-                const double* m, const double* sn2, int vec) {
+                const double* m, const double* sn2, int vec, bool m_const = false) {
+  b.m_const = m_const;
   b.S = S;
   b.N = c->N;
   b.D = c->D;
@@ -2401,7 +2457,7 @@ void gpc_destroy(gpc_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->st);
-  DevBuf* bufs[] = {&c->dX,   &c->mA,    &c->mW,  &c->mT,   &c->xs,   &c->spb,  &c->mulb, &c->divb,
+  DevBuf* bufs[] = {&c->dX,   &c->dY,  &c->mA,    &c->mW,  &c->mT,   &c->xs,   &c->spb,  &c->mulb, &c->divb,
                     &c->dvec, &c->rvec,  &c->zvec, &c->avec, &c->scal, &c->parts, &c->gout, &c->diagq,
                     &c->dmb,  &c->dsn2b, &c->mg,  &c->ng,   &c->ks,   &c->vb,   &c->xss,  &c->pout, &c->kss,
                     &c->dbg1, &c->dbg2,  &c->dbg3, &c->tpart, &c->tile_ctr, &c->rsv_tbl};
@@ -2455,6 +2511,8 @@ int gpc_set_data(gpc_ctx* c, const double* X, const double* y, int N, int D) {
   HIPCHK(c, c->dX.ensure((size_t)N * D * sizeof(double)));
   c->pin.begin();
   HIPCHK(c, c->pin.up(c->dX.p, X, (size_t)N * D * sizeof(double), c->st));
+  HIPCHK(c, c->dY.ensure((size_t)N * sizeof(double)));
+  HIPCHK(c, hipMemcpyAsync(c->dY.p, y, (size_t)N * sizeof(double), hipMemcpyHostToDevice, c->st));
   HIPCHK(c, hipStreamSynchronize(c->st));
   c->hy.assign(y, y + N);
   c->N = N;
@@ -2531,6 +2589,31 @@ int gpc_nll_batch(gpc_ctx* c, int kernel_id, int degree, int dtype, int S, const
   if (dtype == GPC_F64)
     return nll_impl<double>(c, b, want_grad, dm, mean_N, dsn2, noise_N, nlz, dnlz, sn2_mult, L_chol, info);
   return nll_impl<float>(c, b, want_grad, dm, mean_N, dsn2, noise_N, nlz, dnlz, sn2_mult, L_chol, info);
+}
+
+int gpc_nll_batch_cm(gpc_ctx* c, int kernel_id, int degree, int dtype, int S, const double* hyp_cov,
+                     const double* m0, int mean_N, const double* sn2, int sn2_is_vector, int want_grad,
+                     const double* dsn2, int noise_N, double* nlz, double* dnlz, double* sn2_mult, int* L_chol,
+                     int* info) {
+  int rc = check_batch_args(c, kernel_id, degree, dtype, S);
+  if (rc) return rc;
+  if (!hyp_cov || !sn2 || !nlz || !sn2_mult || !L_chol || !info) FAIL(c, "gpc_nll_batch_cm: null argument");
+  if (mean_N < 0 || mean_N > 1 || (mean_N == 1 && !m0)) FAIL(c, "gpc_nll_batch_cm: mean_N must be 0 (zero mean) or 1 (m0 given)");
+  if (want_grad && (!dnlz || (noise_N > 0 && !dsn2))) FAIL(c, "gpc_nll_batch_cm: gradient requested without dnlz/dsn2");
+  HIPCHK(c, hipSetDevice(c->device));
+  HostClock hc("nll");
+  std::vector<double> zero;
+  if (!m0) {
+    zero.assign(S, 0.0);
+    m0 = zero.data();
+  }
+  Batch b;
+  fill_batch(c, b, kernel_id, degree, S, hyp_cov, m0, sn2, sn2_is_vector, true);
+  hc.lap("fill_batch");
+  // dm = nullptr with mean_N = 1: the constant mean's derivative (ones), summed on the device
+  if (dtype == GPC_F64)
+    return nll_impl<double>(c, b, want_grad, nullptr, mean_N, dsn2, noise_N, nlz, dnlz, sn2_mult, L_chol, info);
+  return nll_impl<float>(c, b, want_grad, nullptr, mean_N, dsn2, noise_N, nlz, dnlz, sn2_mult, L_chol, info);
 }
 
 int gpc_posterior_batch(gpc_ctx* c, int kernel_id, int degree, int dtype, int S, const double* hyp_cov,

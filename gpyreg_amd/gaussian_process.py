@@ -247,35 +247,20 @@ class GP:
             ctx.set_data(self.X, self.y, self._token)
         return ctx
 
-    def _plugin_values(self, hyp: np.ndarray, grad: bool):
-        """Evaluate the O(N*D) boundary plugins for every sample
-        (gaussian_process.py:2371-2400): m (S,N), sn2 (S,N|1), dm (S,N,mean_N), dsn2 (S,N|1,noise_N).
+    def _const_mean(self):
+        """The mean is the stock ZeroMean or ConstantMean (exact types: a subclass may compute anything)."""
+        from .mean_functions import ConstantMean, ZeroMean
 
-        The stock plugins evaluate all rows in one NumPy pass (their ``values``; the design stage of
-        ``fit`` hands over 1024 hyperparameter vectors at once).  Exact types only: a subclass or any other
-        object with the reference's protocol is called once per sample through its own ``compute``."""
-        from .mean_functions import ConstantMean, NegativeQuadratic, ZeroMean
+        return type(self.mean) in (ZeroMean, ConstantMean)
+
+    def _noise_values(self, hyp: np.ndarray, grad: bool):
+        """The noise part of ``_plugin_values``: sn2, dsn2 | None, per-point flag."""
         from .noise_functions import GaussianNoise
 
-        cov_N, noise_N, mean_N = self._counts()
-        S, N = hyp.shape[0], self.X.shape[0]
+        cov_N, noise_N, _ = self._counts()
+        S = hyp.shape[0]
         h_noise = hyp[:, cov_N:cov_N + noise_N]
-        h_mean = hyp[:, cov_N + noise_N:cov_N + noise_N + mean_N]
-        dm = dsn2 = None
-        if type(self.mean) in (ZeroMean, ConstantMean, NegativeQuadratic):
-            m = self.mean.values(h_mean, self.X, grad)
-            if grad:
-                m, dm = m
-        else:
-            m, dm_rows = np.empty((S, N)), []
-            for s in range(S):
-                r = self.mean.compute(h_mean[s], self.X, compute_grad=grad)
-                if grad:
-                    r, d = r
-                    if mean_N > 0:
-                        dm_rows.append(np.asarray(d, dtype=float).reshape(N, mean_N))
-                m[s] = np.reshape(r, (-1,))
-            dm = np.stack(dm_rows) if dm_rows else None
+        dsn2 = None
         if type(self.noise) is GaussianNoise:
             sn2 = self.noise.values(h_noise, self.X, self.y, self.s2, grad)
             if grad:
@@ -294,9 +279,39 @@ class GP:
             dsn2 = np.stack(dsn2_rows) if dsn2_rows else None
         if dsn2 is not None and not vec:
             dsn2 = dsn2[:, :1, :]  # a single noise value: the core reads ONE gradient row per sample (:2491-2498)
+        return sn2, (dsn2 if (grad and noise_N > 0) else None), vec
+
+    def _plugin_values(self, hyp: np.ndarray, grad: bool):
+        """Evaluate the O(N*D) boundary plugins for every sample
+        (gaussian_process.py:2371-2400): m (S,N), sn2 (S,N|1), dm (S,N,mean_N), dsn2 (S,N|1,noise_N).
+
+        The stock plugins evaluate all rows in one NumPy pass (their ``values``; the design stage of
+        ``fit`` hands over 1024 hyperparameter vectors at once).  Exact types only: a subclass or any other
+        object with the reference's protocol is called once per sample through its own ``compute``."""
+        from .mean_functions import ConstantMean, NegativeQuadratic, ZeroMean
+
+        cov_N, noise_N, mean_N = self._counts()
+        S, N = hyp.shape[0], self.X.shape[0]
+        h_mean = hyp[:, cov_N + noise_N:cov_N + noise_N + mean_N]
+        dm = None
+        if type(self.mean) in (ZeroMean, ConstantMean, NegativeQuadratic):
+            m = self.mean.values(h_mean, self.X, grad)
+            if grad:
+                m, dm = m
+        else:
+            m, dm_rows = np.empty((S, N)), []
+            for s in range(S):
+                r = self.mean.compute(h_mean[s], self.X, compute_grad=grad)
+                if grad:
+                    r, d = r
+                    if mean_N > 0:
+                        dm_rows.append(np.asarray(d, dtype=float).reshape(N, mean_N))
+                m[s] = np.reshape(r, (-1,))
+            dm = np.stack(dm_rows) if dm_rows else None
+        sn2, dsn2, vec = self._noise_values(hyp, grad)
         return {"m": m, "sn2": sn2, "vec": vec,
                 "dm": dm if (grad and mean_N > 0) else None,
-                "dsn2": dsn2 if (grad and noise_N > 0) else None}
+                "dsn2": dsn2}
 
     def _kid(self):
         return self.covariance._gpc_kernel_id, self.covariance._gpc_degree
@@ -350,8 +365,17 @@ class GP:
     def _nll_batch_local(self, hyp, compute_grad):
         """This rank's evaluation of the rows of ``hyp``: nlZ, dnlZ | None, info (no exception for a
         failed sample: the caller decides, after the exchange when sharded)."""
-        cov_N, _, _ = self._counts()
+        cov_N, noise_N, mean_N = self._counts()
         ctx = self._ctx()
+        if self._builtin and self._const_mean():
+            # the stock zero / constant mean: one value per sample crosses the boundary (gpc_nll_batch_cm), not an
+            # (S, N) array of copies of it and an (S, N, 1) array of ones -- same results, to the bit
+            sn2, dsn2, vec = self._noise_values(hyp, compute_grad)
+            kid, deg = self._kid()
+            m0 = hyp[:, cov_N + noise_N] if mean_N == 1 else None
+            nlz, dnlz, mult, lchol, info = ctx.nll_batch_cm(
+                kid, deg, _DTYPES[self.dtype], hyp[:, :cov_N], m0, sn2, vec, compute_grad, dsn2)
+            return nlz, dnlz, info
         pv = self._plugin_values(hyp, compute_grad)
         if self._builtin:
             kid, deg = self._kid()

@@ -83,6 +83,15 @@ int gpc_nll_batch(gpc_ctx* ctx, int kernel_id, int degree, int dtype, int S,
                   const double* dsn2, int noise_N, double* nlz, double* dnlz,
                   double* sn2_mult, int* L_chol, int* info);
 
+/* ---- the same call for the stock ZeroMean / ConstantMean (mean_functions.py:82-131, :210-260): the mean is ONE value
+ * per sample, m0[S] (mean_N = 1; NULL with mean_N = 0 for the zero mean), and its derivative is all ones -- so neither
+ * m (S x N) nor dm (S x N x 1) crosses the bus: r = y - m0 is formed on the device from the resident y, and with a scalar
+ * noise model so is the diagonal term.  Results are those of gpc_nll_batch with m[s][i] = m0[s], dm = 1, to the bit.     */
+int gpc_nll_batch_cm(gpc_ctx* ctx, int kernel_id, int degree, int dtype, int S, const double* hyp_cov,
+                     const double* m0, int mean_N, const double* sn2, int sn2_is_vector, int want_grad,
+                     const double* dsn2, int noise_N, double* nlz, double* dnlz, double* sn2_mult,
+                     int* L_chol, int* info);
+
 /* ---- the same for ANY covariance object: caller-provided K and dK -------------------------------
  * The reference calls whatever object it was given -- `covariance.compute(hyp, X, compute_grad)`
  * (gaussian_process.py:2388-2390; AbstractKernel, covariance_functions.py:9-20).  A kernel this
