@@ -167,3 +167,38 @@ def test_fused_predict_product_in_fp32_against_fp64():
     assert np.abs(res["f64"][0] - rmu).max() < 1e-8 and np.abs(res["f64"][1] - rs2).max() < 1e-8 * max(1.0, rs2.max())
     assert np.abs(res["f32"][0] - rmu).max() < 1e-3 * max(1.0, np.abs(rmu).max())
     assert np.abs(res["f32"][1] - rs2).max() < 1e-3 * max(1.0, rs2.max())
+
+
+@pytest.mark.parametrize("N", [100, 300])
+def test_many_input_dimensions_through_the_new_kernels(ctx, N):
+    """D = 70: more dimensions than one LDS stage holds (32: the distance sweeps restage), more than the one-leaf
+    pipeline keeps scaling factors for in LDS (64: read from the staged host copy), and an odd count for the packed
+    fp32 sweeps -- NLL and gradient against the oracle in fp64, fp32 against fp64 at 1e-3, predict likewise."""
+    import gpyreg_amd as gpr
+    from oracle import gp_oracle as orc  # checker only
+
+    D, S = 71, 3
+    rng = np.random.default_rng(N + 7)
+    X = rng.uniform(-1, 1, (N, D))
+    y = np.sin(X[:, :3].sum(1, keepdims=True)) + 0.1 * rng.standard_normal((N, 1))
+    hyp = np.concatenate([np.log(6.0) * np.ones(D), [0.0, np.log(0.2), 0.1]]) + 0.05 * rng.standard_normal((S, D + 3))
+    xs = rng.uniform(-1, 1, (9, D))
+    res = {}
+    for dtype in ("f64", "f32"):
+        gp = gpr.GP(D, gpr.covariance_functions.Matern(3), gpr.mean_functions.ConstantMean(),
+                    gpr.noise_functions.GaussianNoise(constant_add=True), dtype=dtype)
+        gp.update(X_new=X, y_new=y, hyp=hyp)
+        res[dtype] = gp.nll_batch(hyp, compute_grad=True) + gp.predict(xs, separate_samples=True)
+    model = dict(kernel="matern", degree=3, mean="const", noise=(1, 0, 0))
+    posts = orc.posteriors(model, hyp, X, y, None)
+    rmu, rs2 = orc.predict(model, posts, X, y, xs, separate_samples=True)
+    nlz, dnlz, mu, s2 = res["f64"]
+    for s in range(S):
+        rn, rd = orc.core(model, hyp[s], X, y, None, 1, 1)
+        assert abs(nlz[s] - rn) <= 1e-8 * max(1.0, abs(rn))
+        assert np.abs(dnlz[s] - rd).max() <= 1e-8 * max(1.0, np.abs(rd).max())
+    assert np.abs(mu - rmu).max() < 1e-8 and np.abs(s2 - rs2).max() < 1e-8
+    n32, d32, mu32, s232 = res["f32"]
+    assert np.abs(n32 - nlz).max() <= 1e-3 * np.abs(nlz).max()
+    assert np.abs(d32 - dnlz).max() <= 1e-3 * np.abs(dnlz).max()
+    assert np.abs(mu32 - mu).max() <= 1e-3 and np.abs(s232 - s2).max() <= 1e-3 * max(1.0, s2.max())
