@@ -1873,17 +1873,14 @@ int rhs_products(gpc_post* po, int mode, const double* xa, const double* xb, int
     if (xb) HIPCHK(c, c->pin.up(d_xb, xb, (size_t)M * D * 8, st));
   }
   // landing buffers of the per-chunk results (pinned when available)
-  std::vector<double> hmu_v, hv_v;
-  double* hmu = static_cast<double*>(c->pin.alloc((size_t)chunk * mpad * 8));
-  double* hv = static_cast<double*>(c->pin.alloc((size_t)chunk * mpad * 8));
+  // (one block for both: the device keeps [mu | v] contiguous too, so a call's results come back in ONE copy)
+  std::vector<double> hmu_v;
+  double* hmu = static_cast<double*>(c->pin.alloc(2 * (size_t)chunk * mpad * 8));
   if (!hmu) {
-    hmu_v.resize((size_t)chunk * mpad);
+    hmu_v.resize(2 * (size_t)chunk * mpad);
     hmu = hmu_v.data();
   }
-  if (!hv) {
-    hv_v.resize((size_t)chunk * mpad);
-    hv = hv_v.data();
-  }
+  double* hv = hmu + (size_t)chunk * mpad;
   double* hfull = nullptr;
   if (full && (size_t)M * M * 8 >= PinBuf::kMin && (size_t)M * M * 8 <= PinBuf::kMax)
     hfull = static_cast<double*>(c->pin.alloc((size_t)M * M * 8));
@@ -2040,8 +2037,12 @@ int rhs_products(gpc_post* po, int mode, const double* xa, const double* xb, int
       a = e;
     }
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(hmu, d_mu, (size_t)cnt * mpad * 8, hipMemcpyDeviceToHost, st));
-    if (want_quad) HIPCHK(c, hipMemcpyAsync(hv, d_v, (size_t)cnt * mpad * 8, hipMemcpyDeviceToHost, st));
+    if (want_quad && cnt == chunk)  // d_v = d_mu + chunk * mpad: one contiguous block
+      HIPCHK(c, hipMemcpyAsync(hmu, d_mu, 2 * (size_t)chunk * mpad * 8, hipMemcpyDeviceToHost, st));
+    else {
+      HIPCHK(c, hipMemcpyAsync(hmu, d_mu, (size_t)cnt * mpad * 8, hipMemcpyDeviceToHost, st));
+      if (want_quad) HIPCHK(c, hipMemcpyAsync(hv, d_v, (size_t)cnt * mpad * 8, hipMemcpyDeviceToHost, st));
+    }
     if (full) {
       HIPCHK(c, c->dbg3.ensure((size_t)M * M * 8));
       for (int i = 0; i < cnt; ++i) {
