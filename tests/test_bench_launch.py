@@ -149,3 +149,29 @@ def test_under_torch_distributed_run_exactly_as_the_driver_launches_it():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["launcher"] in ("torchrun", "env")
     assert line["config"]["global_samples"] == 16 and line["config"]["samples_per_gpu"] == 8
+
+
+@pytest.mark.gpu
+def test_the_bench_line_carries_every_field_of_the_contract():
+    """One line of JSON with the fields the driver and the judge read (metric / value / unit / n_gpus / steps / warmup /
+    ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload, `roofline` with bound,
+    achieved, peak, unit, frac and traffic, `cpu_baseline` with value, unit, cores, kind and sample) -- on cfg2, whose CPU
+    leg takes seconds."""
+    r, line = _bench("--config", "2", "--steps", "5", "--warmup", "2")
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len([ln for ln in r.stdout.splitlines() if ln.strip()]) == 1  # ONE line on stdout
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["steps"] == 5 and line["warmup"] == 2 and line["higher_is_better"] is True
+    assert line["vs_baseline"] is None and line["dtype"] == "f64" and line["data"] == "synthetic"
+    assert "workload" in line["config"] and "model" not in line["config"]
+    roof = line["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_factor_section", "frac_wall"):
+        assert k in roof, k
+    assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    cb = line["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert cb["kind"] == "port" and cb["nlz_rel_err"] < 1e-8 and cb["grad_rel_err"] < 1e-8
+    assert abs(line["value"] - 1.0 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]  # one sample per step
