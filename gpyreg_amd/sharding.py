@@ -43,9 +43,32 @@ def _dist():
     return dist
 
 
+# Buffers of the exchanges, reused from call to call: a gather is a few hundred bytes per rank, so what it costs is the
+# host work around the collective (tools/exchange_probe.py: 59 us to issue and 90-120 us to complete one with freshly
+# allocated tensors, a pageable upload and `.cpu()`; two per sharded call).  Per (rows, columns, world, device): the
+# device block and result, and pinned host images of both (asynchronous copies either way).  A set is taken for the
+# life of one _Gather and handed back by `result`, so two gathers in flight never share one.
+_POOL = {}
+
+
+def _buffers(maxrows, C, world, dev):
+    import torch
+
+    key = (maxrows, C, world, str(dev))
+    free = _POOL.setdefault(key, [])
+    if free:
+        return key, free.pop()
+    cuda = dev.type == "cuda"
+    buf = torch.zeros((maxrows, C), dtype=torch.float64, device=dev)
+    out = torch.empty((world * maxrows, C), dtype=torch.float64, device=dev)
+    hin = torch.zeros((maxrows, C), dtype=torch.float64, pin_memory=cuda) if cuda else None
+    hout = torch.empty((world * maxrows, C), dtype=torch.float64, pin_memory=cuda) if cuda else None
+    return key, (buf, out, hin, hout)
+
+
 class _Gather:
-    """An all-gather of row blocks in flight: ``start`` issues it (asynchronously), ``result`` waits and returns the
-    full (S, C) array.  RCCL over xGMI when the backend is nccl."""
+    """An all-gather of row blocks in flight: the constructor issues it (asynchronously), ``result`` waits and returns
+    the full (S, C) array.  RCCL over xGMI when the backend is nccl."""
 
     def __init__(self, local: np.ndarray, S: int, group=None):
         import torch
@@ -57,20 +80,38 @@ class _Gather:
         self.maxrows = -(-S // self.world)
         backend = dist.get_backend(group)
         dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-        buf = torch.zeros((self.maxrows, C), dtype=torch.float64, device=dev)
-        buf[: local.shape[0]] = torch.from_numpy(np.ascontiguousarray(local)).to(dev)
-        self.out = torch.empty((self.world * self.maxrows, C), dtype=torch.float64, device=dev)
-        self.buf = buf  # kept alive until the collective has completed
-        self.work = dist.all_gather_into_tensor(self.out, buf, group=group, async_op=True)
+        self.key, (buf, out, hin, hout) = _buffers(self.maxrows, C, self.world, dev)
+        n = local.shape[0]
+        src = torch.from_numpy(np.ascontiguousarray(local, dtype=np.float64))
+        if hin is not None:  # device group: through the pinned image, asynchronously on the current stream
+            hin.zero_()
+            hin[:n] = src
+            buf.copy_(hin, non_blocking=True)
+        else:
+            buf.zero_()
+            buf[:n] = src
+        self.bufs = (buf, out, hin, hout)  # held until the collective has completed
+        self.work = dist.all_gather_into_tensor(out, buf, group=group, async_op=True)
 
     def result(self) -> np.ndarray:
+        import torch
+
+        buf, out, hin, hout = self.bufs
         self.work.wait()
-        out = self.out.cpu().numpy().reshape(self.world, self.maxrows, -1)
+        if hout is not None:
+            hout.copy_(out, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            full = hout.numpy().reshape(self.world, self.maxrows, -1)
+        else:
+            full = out.numpy().reshape(self.world, self.maxrows, -1)
         rows = []
         for r in range(self.world):
             lo, hi = shard_bounds(self.S, r, self.world)
-            rows.append(out[r, : hi - lo])
-        return np.concatenate(rows, axis=0)
+            rows.append(full[r, : hi - lo])
+        res = np.concatenate(rows, axis=0)  # (a copy: the buffers go back to the pool)
+        _POOL[self.key].append(self.bufs)
+        self.bufs = None
+        return res
 
 
 def _all_gather_rows(local: np.ndarray, S: int, group=None) -> np.ndarray:

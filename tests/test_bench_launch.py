@@ -119,7 +119,7 @@ def test_the_rccl_branch_with_one_rank():
         "from gpyreg_amd import sharding as sh\n"
         "a = np.arange(12.0).reshape(4, 3)\n"
         "g = sh._Gather(a, 4)\n"
-        "assert g.out.is_cuda and np.array_equal(g.result(), a)\n"
+        "assert g.bufs[1].is_cuda and np.array_equal(g.result(), a)\n"
         "dist.barrier(); dist.destroy_process_group(); print('gather ok')\n" % ROOT)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
