@@ -319,6 +319,69 @@ def _committed_traffic():
     return {}, None
 
 
+def both_splits(args, world, dist, dev, S_arg, evaluate, sync, grad):
+    """Multi-rank runs carry BOTH splits of the batch and the single-GPU yardstick in one job, so
+    that a scaling record separates "exchange cost" from "small-batch inefficiency" without a second launch.  After the
+    timed region, every rank runs `steps` extra steps of each:
+      other split   the split the headline did NOT use -- weak (the configuration's S samples on EVERY rank, sharded call)
+                    when the headline is BASELINE's strong split, and vice versa -- max over ranks;
+      expected      the same two batches of THIS rank evaluated rank-locally (gp.shard = False: no process group inside
+                    the call) -- what one GPU needs for its block when nothing is exchanged -- max over ranks.
+    `evaluate(hyp, shard)` runs one step; reference loops being split: f_min_fill.py:174-176, gaussian_process.py:876-879."""
+    import torch
+
+    from gpyreg_amd import sharding as _sh
+
+    rank = dist.get_rank() if dist is not None else 0
+    S_strong, S_weak = S_arg, S_arg * world
+    out = {}
+
+    def timed(hyp, shard, collective):
+        evaluate(hyp, shard)  # warm-up of this shape
+        if collective:
+            sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            evaluate(hyp, shard)
+        if collective:
+            sync()
+        dt = (time.perf_counter() - t0) / args.steps
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t[0].item())
+        return dt
+
+    other = "weak" if args.scaling != "weak" else "strong"
+    S_other = S_weak if other == "weak" else S_strong
+    _, _, hyp_o = synthetic_problem(args.config, S_other)
+    dt = timed(hyp_o, True, True)
+    per = [_sh.shard_bounds(S_other, r, world)[1] - _sh.shard_bounds(S_other, r, world)[0] for r in range(world)]
+    out[other] = {"value": S_other / dt, "unit": "fit-evals/s" if grad else "NLL evals/s", "ms_per_step": dt * 1e3,
+                  "global_samples": S_other, "samples_per_gpu": per[0] if len(set(per)) == 1 else per,
+                  "steps": args.steps, "timing": "max over ranks, barrier + device sync on both sides"}
+    exp = {}
+    for name, S in (("strong", S_strong), ("weak", S_weak)):
+        _, _, hyp_s = synthetic_problem(args.config, S)
+        lo, hi = _sh.shard_bounds(S, rank, world)
+        dt = timed(hyp_s[lo:hi], False, False) if hi > lo else 0.0
+        if hi <= lo and dist is not None:  # a rank without rows still joins the reduction
+            t = torch.tensor([0.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t[0].item())
+        exp[name] = {"ms_per_step": dt * 1e3, "samples": max(per_r(S, world)), "value_if_no_exchange": S / dt if dt > 0 else None}
+    exp["how"] = ("this rank's block of each split evaluated rank-locally in the same process (gp.shard = False), "
+                  "max over ranks; the sharded figures above minus these are the exchange and the wait for the slowest rank")
+    out["expected_from_1gpu"] = exp
+    return out
+
+
+def per_r(S, world):
+    from gpyreg_amd import sharding as _sh
+
+    return [_sh.shard_bounds(S, r, world)[1] - _sh.shard_bounds(S, r, world)[0] for r in range(world)]
+
+
 def dry_run(args, world, rank):
     """Rehearsal of the launcher and of the sharded exchange WITHOUT device work (runs on a machine without a GPU:
     tests/test_bench_launch.py): the ranks form the process group, partition the configuration's batch exactly as
@@ -347,9 +410,23 @@ def dry_run(args, world, rank):
         full, bad = _sh.gather_rows(S_global, C, local, None, _sh.fingerprint(hyp))
     assert full.shape == (S_global, C) and np.array_equal(full[:, 1:], 2.0 * hyp) and not bad.any()
     per_rank = [_sh.shard_bounds(S_global, r, world)[1] - _sh.shard_bounds(S_global, r, world)[0] for r in range(world)]
+    splits = {}
+    calls_per_step = _sh.stats()["calls"] / (args.warmup + args.steps)
+    if dist.is_initialized():
+        import torch
+
+        def evaluate(h, shard):  # the same stand-in rows, sharded through the exchange or rank-local
+            def loc(lo, hi):
+                return np.concatenate([h[lo:hi].sum(1, keepdims=True), 2.0 * h[lo:hi]], axis=1), np.zeros(hi - lo, bool)
+            if shard:
+                return _sh.gather_rows(h.shape[0], 1 + h.shape[1], loc, None, _sh.fingerprint(h))
+            return loc(0, h.shape[0])
+
+        splits = both_splits(args, world, dist, torch.device("cpu"), S_arg, evaluate, dist.barrier, True)
     if dist.is_initialized():
         dist.barrier()
     if rank == 0:
+        extra = {k: v for k, v in splits.items()}
         print(json.dumps({
             "metric": "launcher rehearsal (no device work)", "value": None, "unit": None, "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "scaling": "weak" if args.scaling == "weak" else "strong",
@@ -358,7 +435,7 @@ def dry_run(args, world, rank):
                 "samples_per_gpu": per_rank[0] if len(set(per_rank)) == 1 else per_rank,
                 "launcher": os.environ.get("BENCH_LAUNCHER", "env" if "RANK" in os.environ else "single process"),
                 "backend": "gloo" if dist.is_initialized() else None, "process_group_ranks": world,
-                "exchanges_per_step": _sh.stats()["calls"] / (args.warmup + args.steps)}}), flush=True)
+                "exchanges_per_step": calls_per_step, **extra}}), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
 
@@ -461,6 +538,19 @@ def run(args):
     else:
         exch_max = exch["seconds"]
 
+    # both splits and the single-GPU yardstick in the same job (multi-rank runs; after the timed region)
+    splits = {}
+    if dist is not None and world > 1 and mode != "predict":
+        def evaluate(h, shard):
+            prev = gp.shard
+            gp.shard = shard
+            try:
+                return gp.nll_batch(h, compute_grad=grad)
+            finally:
+                gp.shard = prev
+
+        splits = both_splits(args, world, dist, dev, S_arg, evaluate, sync, grad)
+
     # The dominant single kernel, timed ALONE as well: three extra UNTIMED steps with one sample group and the two
     # triangular mat-vecs after the launch instead of under it (they cost it ~3 %), so that its hipEvent
     # time is the kernel's own duration; the first of the three is dropped.
@@ -515,11 +605,12 @@ def run(args):
         "devices": devices,
         "distinct_devices": len(set(devices)),
         # the exchange step of a sharded call, as rank 0 / the slowest rank saw it: waiting for the slowest rank,
-        # the two all-gathers (agreement row, data rows) and their host <-> device copies
+        # the all-gather of the frame (header + rows, gpyreg_amd/sharding.py) and its host <-> device copies
         "exchange_ms_per_step": None if dist is None else exch["seconds"] / args.steps * 1e3,
         "exchange_ms_per_step_max_over_ranks": None if dist is None else exch_max / args.steps * 1e3,
         "exchanges_per_step": None if dist is None else exch["calls"] / args.steps,
     }
+    config.update(splits)  # "weak" (or "strong") and "expected_from_1gpu" when there is more than one rank
 
     if mode == "predict":
         mu, s2 = r0, r1

@@ -44,19 +44,32 @@ def _dist():
 
 
 # Buffers of the exchanges, reused from call to call: a gather is a few hundred bytes per rank, so what it costs is the
-# host work around the collective (tools/exchange_probe.py: 59 us to issue and 90-120 us to complete one with freshly
-# allocated tensors, a pageable upload and `.cpu()`; two per sharded call).  Per (rows, columns, world, device): the
-# device block and result, and pinned host images of both (asynchronous copies either way).  A set is taken for the
-# life of one _Gather and handed back by `result`, so two gathers in flight never share one.
-_POOL = {}
+# host work around the collective (tools/exchange_probe.py, profiles/r04_exchange_probe.txt: 59 us to issue and 90-120 us
+# to complete one with freshly allocated tensors, a pageable upload and `.cpu()`).  Per (rows, columns, world, device):
+# the device block and result, and pinned host images of both (asynchronous copies either way).  A set is taken for the
+# life of one _Gather and handed back when it ends -- by `result`, also when the wait raises -- so two gathers in flight
+# never share one.  ONLY small, fixed shapes are pooled: the frame of `gather_rows` and blocks up to
+# _POOL_MAX_BYTES; the gathers of predict / predict_full / quad, whose width is the number of query points, take fresh
+# buffers and drop them, and the pool as a whole is capped at _POOL_BUDGET bytes (least recently used sets go first).
+_POOL = {}  # key -> list of free buffer sets; dict order = recency of use
+_POOL_MAX_BYTES = 64 << 10   # per-rank block size up to which a shape is pooled
+_POOL_BUDGET = 8 << 20       # bytes of device (and as many pinned host) memory the free sets may hold
+_pool_bytes = [0]
+
+
+def _set_bytes(key):
+    maxrows, C, world, _ = key
+    return (world + 1) * maxrows * C * 8
 
 
 def _buffers(maxrows, C, world, dev):
     import torch
 
     key = (maxrows, C, world, str(dev))
-    free = _POOL.setdefault(key, [])
+    free = _POOL.get(key)
     if free:
+        _POOL[key] = _POOL.pop(key)  # most recently used
+        _pool_bytes[0] -= _set_bytes(key)
         return key, free.pop()
     cuda = dev.type == "cuda"
     buf = torch.zeros((maxrows, C), dtype=torch.float64, device=dev)
@@ -66,52 +79,83 @@ def _buffers(maxrows, C, world, dev):
     return key, (buf, out, hin, hout)
 
 
+def _give_back(key, bufs):
+    if key[0] * key[1] * 8 > _POOL_MAX_BYTES:
+        return  # a large, caller-shaped gather: not kept
+    _POOL.setdefault(key, []).append(bufs)
+    _POOL[key] = _POOL.pop(key)
+    _pool_bytes[0] += _set_bytes(key)
+    while _pool_bytes[0] > _POOL_BUDGET and _POOL:
+        old = next(iter(_POOL))
+        if _POOL[old]:
+            _POOL[old].pop()
+            _pool_bytes[0] -= _set_bytes(old)
+        if not _POOL[old]:
+            del _POOL[old]
+
+
+def pool_bytes() -> int:
+    """Bytes of device memory (and as many of pinned host memory) held by the free buffer sets of the exchanges."""
+    return _pool_bytes[0]
+
+
 class _Gather:
     """An all-gather of row blocks in flight: the constructor issues it (asynchronously), ``result`` waits and returns
-    the full (S, C) array.  RCCL over xGMI when the backend is nccl."""
+    the full (S, C) array.  RCCL over xGMI when the backend is nccl.  ``raw=True``: ``result`` returns the
+    (world, maxrows, C) block as gathered (a copy), without cutting the rows of each rank to its share."""
 
-    def __init__(self, local: np.ndarray, S: int, group=None):
+    def __init__(self, local: np.ndarray, S: int, group=None, raw: bool = False):
         import torch
 
         dist = _dist()
-        self.S, self.group = S, group
+        self.S, self.group, self.raw = S, group, raw
         self.world = dist.get_world_size(group)
         C = local.shape[1]
         self.maxrows = -(-S // self.world)
         backend = dist.get_backend(group)
         dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
         self.key, (buf, out, hin, hout) = _buffers(self.maxrows, C, self.world, dev)
-        n = local.shape[0]
-        src = torch.from_numpy(np.ascontiguousarray(local, dtype=np.float64))
-        if hin is not None:  # device group: through the pinned image, asynchronously on the current stream
-            hin.zero_()
-            hin[:n] = src
-            buf.copy_(hin, non_blocking=True)
-        else:
-            buf.zero_()
-            buf[:n] = src
         self.bufs = (buf, out, hin, hout)  # held until the collective has completed
-        self.work = dist.all_gather_into_tensor(out, buf, group=group, async_op=True)
+        try:
+            n = local.shape[0]
+            src = torch.from_numpy(np.ascontiguousarray(local, dtype=np.float64))
+            if hin is not None:  # device group: through the pinned image, asynchronously on the current stream
+                if n < self.maxrows:
+                    hin[n:].zero_()
+                hin[:n] = src
+                buf.copy_(hin, non_blocking=True)
+            else:
+                if n < self.maxrows:
+                    buf[n:].zero_()
+                buf[:n] = src
+            self.work = dist.all_gather_into_tensor(out, buf, group=group, async_op=True)
+        except BaseException:
+            self.bufs = None  # (not handed back: their state is unknown)
+            raise
 
     def result(self) -> np.ndarray:
         import torch
 
         buf, out, hin, hout = self.bufs
-        self.work.wait()
-        if hout is not None:
-            hout.copy_(out, non_blocking=True)
-            torch.cuda.current_stream().synchronize()
-            full = hout.numpy().reshape(self.world, self.maxrows, -1)
-        else:
-            full = out.numpy().reshape(self.world, self.maxrows, -1)
-        rows = []
-        for r in range(self.world):
-            lo, hi = shard_bounds(self.S, r, self.world)
-            rows.append(full[r, : hi - lo])
-        res = np.concatenate(rows, axis=0)  # (a copy: the buffers go back to the pool)
-        _POOL[self.key].append(self.bufs)
-        self.bufs = None
-        return res
+        try:
+            self.work.wait()
+            if hout is not None:
+                hout.copy_(out, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+                full = hout.numpy().reshape(self.world, self.maxrows, -1)
+            else:
+                full = out.numpy().reshape(self.world, self.maxrows, -1)
+            if self.raw:
+                return full.copy()
+            rows = []
+            for r in range(self.world):
+                lo, hi = shard_bounds(self.S, r, self.world)
+                rows.append(full[r, : hi - lo])
+            return np.concatenate(rows, axis=0)  # (a copy: the buffers go back to the pool)
+        finally:
+            # the collective has completed or failed: either way nothing is in flight on these buffers any more
+            _give_back(self.key, self.bufs)
+            self.bufs = None
 
 
 def _all_gather_rows(local: np.ndarray, S: int, group=None) -> np.ndarray:
@@ -152,71 +196,109 @@ def fingerprint(*arrays) -> float:
     return float(crc)
 
 
+# Every sharded call opens with ONE gather of a fixed shape, the frame: FRAME doubles per rank whatever the batch --
+# [S, ncols, token, status, payload ...].  A fixed shape cannot disagree between ranks, so no separate agreement
+# exchange has to come first: results of up to FRAME - 4 doubles per rank (cfg3: 2 rows x 15, cfg5: 8 x 13, the
+# 1024-point design of fit on 8 GPUs: 128 x 2) ride in the frame itself, after the local computation -- one collective
+# per call (round 4: two; profiles/r05_exchange_probe.txt).  Larger results (predictions at many points) send the frame
+# BEFORE the local computation, header only, so that it completes under it, and their rows in a second gather once the
+# shapes are known to agree.
+FRAME = 512
+_HDR = 4
+
+
+def _disagreement(seen, world, err):
+    detail = ", ".join(f"rank {r}: S={int(seen[r, 0])} cols={int(seen[r, 1])} crc={int(seen[r, 2]):08x}"
+                       for r in range(world))
+    return ShardError(
+        "the ranks of a sharded evaluation were called with different batches (" + detail + "). Every rank "
+        "must pass the same hyperparameter rows: seed NumPy's global RNG identically on all ranks before "
+        "GP.fit, or set gp.shard = False to keep this GP rank-local")
+
+
 def gather_rows(S: int, ncols: int, compute_local, group=None, token: float = 0.0):
     """Run ``compute_local(lo, hi) -> (rows (hi-lo, ncols), bad (hi-lo,) bool)`` on this rank's block
     and return the full ``(S, ncols)`` array and the full ``bad`` mask on every rank.
 
     A rank whose block raises does NOT leave the others waiting in the collective: the exception is
-    caught, the rank still enters the exchange with a status row, and every rank raises
+    caught, the rank still enters the exchange with its status set, and every rank raises
     ``ShardError`` afterwards (a non-positive-definite sample on one shard is an expected event
     during fitting; it must not become a hang).
 
-    The ranks must have been called with the SAME batch.  An agreement row (fixed shape, exchanged
-    asynchronously UNDER the local computation) carries S, ncols and ``token`` -- the caller's
-    ``fingerprint`` of the full argument arrays: if they differ between ranks (unsynchronised RNG seeds
-    in ``fit``, a speculative batch of another length) every rank raises ``ShardError`` before the data
-    exchange, whose buffer shapes would disagree -- instead of silently stitching together rows of
-    different batches.  One blocking collective per call: the data exchange, which also carries a status
-    row per rank."""
+    The ranks must have been called with the SAME batch.  The frame (fixed shape, see FRAME) carries S,
+    ncols and ``token`` -- the caller's ``fingerprint`` of the full argument arrays: if they differ
+    between ranks (unsynchronised RNG seeds in ``fit``, a speculative batch of another length) every rank
+    raises ``ShardError`` -- before any exchange whose buffer shapes would disagree -- instead of silently
+    stitching together rows of different batches."""
+    import time
+
     rw = active_group(group)
     if rw is None:
         rows, bad = compute_local(0, S)
         return np.asarray(rows, dtype=float).reshape(S, ncols), np.asarray(bad, dtype=bool)
     rank, world = rw
     lo, hi = shard_bounds(S, rank, world)
-    # 1. the agreement exchange -- one fixed-shape row per rank: [S, ncols, fingerprint of the arguments] -- is issued
-    #    BEFORE the local computation and completes under it
-    agreement = _Gather(np.array([[float(S), float(ncols), float(token)]]), world, group)
-    # 2. this rank's block
-    local = np.zeros((hi - lo, ncols + 1))
-    err = None
-    try:
-        if hi > lo:
-            rows, bad = compute_local(lo, hi)
-            local[:, :ncols] = np.asarray(rows, dtype=float).reshape(hi - lo, ncols)
-            local[:, ncols] = np.asarray(bad, dtype=float)
-    except Exception as e:  # noqa: BLE001 - exchanged, then raised on every rank
-        err = e
-        local[:] = 0.0
-    # 3. every rank sees the same agreement rows and takes the same branch
-    import time
-
-    t_exchange = time.perf_counter()
-    seen = agreement.result()
-    if np.any(seen != seen[0]):
-        detail = ", ".join(f"rank {r}: S={int(seen[r, 0])} cols={int(seen[r, 1])} crc={int(seen[r, 2]):08x}"
-                           for r in range(world))
-        raise ShardError(
-            "the ranks of a sharded evaluation were called with different batches (" + detail + "). Every rank "
-            "must pass the same hyperparameter rows: seed NumPy's global RNG identically on all ranks before "
-            "GP.fit, or set gp.shard = False to keep this GP rank-local") from err
-    # 4. the data exchange (shapes agree now): the rank's rows plus ONE status row, so that a rank with an empty block
-    #    that failed is heard too.  Blocks are padded to the same height; the status row rides at index maxrows.
     maxrows = -(-S // world)
-    block = np.zeros((maxrows + 1, ncols + 1))
-    block[: hi - lo] = local
-    block[maxrows, ncols] = 0.0 if err is None else 1.0
-    gathered = _Gather(block, world * (maxrows + 1), group).result().reshape(world, maxrows + 1, ncols + 1)
-    _stats["seconds"] += time.perf_counter() - t_exchange
-    _stats["calls"] += 1
+    header = np.array([float(S), float(ncols), float(token), 0.0])
+    in_frame = maxrows * (ncols + 1) <= FRAME - _HDR
+
+    def run_local():
+        local = np.zeros((hi - lo, ncols + 1))
+        try:
+            if hi > lo:
+                rows, bad = compute_local(lo, hi)
+                local[:, :ncols] = np.asarray(rows, dtype=float).reshape(hi - lo, ncols)
+                local[:, ncols] = np.asarray(bad, dtype=float)
+            return local, None
+        except Exception as e:  # noqa: BLE001 - exchanged, then raised on every rank
+            local[:] = 0.0
+            return local, e
+
+    def stitch(block_of):
+        full = np.concatenate([block_of(r)[: shard_bounds(S, r, world)[1] - shard_bounds(S, r, world)[0]]
+                               for r in range(world)], axis=0)
+        return full[:, :ncols].copy(), full[:, ncols] != 0.0
+
+    frame = np.zeros((1, FRAME))
+    frame[0, :_HDR] = header
+    if in_frame:
+        # ONE collective: this rank's rows and its status ride in the frame, after the local computation
+        local, err = run_local()
+        t_exchange = time.perf_counter()
+        frame[0, 3] = 0.0 if err is None else 1.0
+        frame[0, _HDR:_HDR + local.size] = local.ravel()
+        seen = _Gather(frame, world, group, raw=True).result().reshape(world, FRAME)
+        _stats["seconds"] += time.perf_counter() - t_exchange
+        _stats["calls"] += 1
+        if np.any(seen[:, :3] != seen[0, :3]):
+            raise _disagreement(seen, world, err) from err
+        status = seen[:, 3]
+        block_of = lambda r: seen[r, _HDR:_HDR + maxrows * (ncols + 1)].reshape(maxrows, ncols + 1)  # noqa: E731
+    else:
+        # the frame (header only) is issued BEFORE the local computation and completes under it; the rows follow in a
+        # second gather once every rank is known to hold the same shapes
+        agreement = _Gather(frame, world, group, raw=True)
+        local, err = run_local()
+        t_exchange = time.perf_counter()
+        seen = agreement.result().reshape(world, FRAME)
+        if np.any(seen[:, :3] != seen[0, :3]):
+            raise _disagreement(seen, world, err) from err
+        # blocks are padded to the same height; ONE status row per rank rides at index maxrows, so that a rank with an
+        # empty block that failed is heard too
+        block = np.zeros((maxrows + 1, ncols + 1))
+        block[: hi - lo] = local
+        block[maxrows, ncols] = 0.0 if err is None else 1.0
+        gathered = _Gather(block, world * (maxrows + 1), group, raw=True).result()
+        _stats["seconds"] += time.perf_counter() - t_exchange
+        _stats["calls"] += 1
+        status = gathered[:, maxrows, ncols]
+        block_of = lambda r: gathered[r]  # noqa: E731
     if err is not None:
         raise ShardError(f"rank {rank}: {type(err).__name__}: {err}") from err
-    failed = [r for r in range(world) if gathered[r, maxrows, ncols] != 0.0]
+    failed = [r for r in range(world) if status[r] != 0.0]
     if failed:
         raise ShardError(f"sharded evaluation failed on rank(s) {failed}")
-    full = np.concatenate([gathered[r, : shard_bounds(S, r, world)[1] - shard_bounds(S, r, world)[0]]
-                           for r in range(world)], axis=0)
-    return full[:, :ncols].copy(), full[:, ncols] != 0.0
+    return stitch(block_of)
 
 
 def nll_batch_sharded(gp, hyp: np.ndarray, compute_grad: bool = False, group=None):

@@ -23,6 +23,9 @@ Reference lines followed (paths relative to the reference checkout):
   gaussian_process.py:1663-1816     GP.predict
   gaussian_process.py:870-884       GP.update full-recompute loop
   gaussian_process.py:750-844       GP.update rank-one path (one new point)
+  core_streamed: the same core with the gradient planes of covariance_functions.py:177-184, :267-283,
+                 :349-363 (isotropic :149-158, :216-218) formed ONE AT A TIME instead of as an (N, N, cov_N)
+                 tensor -- the only way to a gradient at cfg4 (N = 16384, 22 planes = 47 GB in the reference)
 
 Third-party arithmetic the reference delegates to (source not in the reference
 tree): scipy.spatial.distance.{pdist,cdist,squareform}, scipy.linalg.{cholesky,
@@ -231,6 +234,77 @@ def covariance(
     raise ValueError(kernel)
 
 
+def covariance_planes(kernel: str, hyp: np.ndarray, X: np.ndarray, degree: int = 0):
+    """Generator: first K, then dK[:, :, 0], dK[:, :, 1], ... -- each plane a fresh C-contiguous (N, N) array
+    holding exactly the values ``covariance(..., compute_grad=True)`` puts into that plane (the same SciPy calls
+    on the same arguments; factors that the reference recomputes inside its loop over dimensions --
+    ``sf2 * (df(tmp) * exp(-tmp))`` at covariance_functions.py:280, ``sf2 * M ** (-alpha - 1)`` at :357 -- are
+    evaluated once: same operands, same operations, same bits).  Never more than one plane alive, so the
+    gradient of a problem whose (N, N, cov_N) tensor does not fit in memory can still be formed with the
+    reference's arithmetic.  Pinned plane by plane against cov_cases.npz (tests/test_oracle_golden.py)."""
+    N, D = X.shape
+    cov_N = cov_count(kernel, D)
+    if hyp.size != cov_N or hyp.ndim != 1:
+        raise ValueError("covariance_planes: one hyperparameter vector of the kernel's size")
+    iso = kernel.endswith("_iso")
+    if iso:
+        ell = np.exp(hyp[0])
+        sf2 = np.exp(2 * hyp[1])
+    else:
+        ell = np.exp(hyp[0:D])
+        sf2 = np.exp(2 * hyp[D])
+
+    def one_dim(scale_i, i):  # the per-dimension squared distance of :179-181, :268-275, :350-355
+        return squareform(pdist(np.reshape(scale_i * X[:, i], (-1, 1)), "sqeuclidean"))
+
+    if kernel in ("se", "se_iso"):
+        tmp = squareform(pdist(X / ell, "sqeuclidean"))
+        K = sf2 * np.exp(-tmp / 2)
+        yield K
+        if iso:
+            yield K * tmp  # isotropic :216 recomputes the same squareform(pdist(X / ell))
+        else:
+            del tmp
+            for i in range(D):  # :177-181 divides: X[:, i] / ell[i]
+                yield K * squareform(pdist(np.reshape(X[:, i] / ell[i], (-1, 1)), "sqeuclidean"))
+        yield 2 * K
+        return
+    if kernel in ("matern", "matern_iso"):
+        f, df = _matern_f_df(degree)
+        if iso:
+            tmp = squareform(pdist(X * np.sqrt(degree) / ell))
+        else:
+            tmp = squareform(pdist(X @ np.diag(np.sqrt(degree) / ell)))
+        K = sf2 * f(tmp) * np.exp(-tmp)
+        yield K
+        with np.errstate(all="ignore"):
+            G = sf2 * (df(tmp) * np.exp(-tmp))
+            del tmp
+            if iso:
+                yield G * squareform(pdist(np.sqrt(degree) / ell * X, "sqeuclidean"))
+            else:
+                for i in range(D):
+                    yield G * one_dim(np.sqrt(degree) / ell[i], i)
+            del G
+        yield 2 * K
+        return
+    if kernel == "rq":
+        alpha = np.exp(hyp[D + 1])
+        tmp = squareform(pdist(X @ np.diag(1.0 / ell), "sqeuclidean"))
+        M = 1 + 0.5 * tmp / alpha
+        K = sf2 * M ** (-alpha)
+        yield K
+        with np.errstate(all="ignore"):
+            G = sf2 * M ** (-alpha - 1)
+            for i in range(D):
+                yield G * one_dim(1.0 / ell[i], i)
+            del G
+        yield 2 * K
+        yield K * (0.5 * tmp / M - alpha * np.log(M))
+        return
+    raise ValueError(kernel)
+
+
 # --------------------------------------------------------------------------
 # noise and mean (boundary plugins, O(N*D))
 # --------------------------------------------------------------------------
@@ -331,10 +405,14 @@ class OraclePosterior:
         self.L_chol = L_chol
 
 
-def core(model, hyp, X, y, s2, compute_nlZ, compute_nlZ_grad, force_mult=None):
+def core(model, hyp, X, y, s2, compute_nlZ, compute_nlZ_grad, force_mult=None, streamed=False):
     """model = dict(kernel=..., degree=..., mean=..., noise=(c,u,r)).
 
     Returns nlZ | (nlZ, dnlZ) | OraclePosterior exactly like the reference.
+
+    ``streamed`` (see ``core_streamed``): the covariance gradient is contracted plane by plane from
+    ``covariance_planes`` instead of from the materialised (N, N, cov_N) tensor; everything else is this very
+    code path.
 
     ``force_mult`` (test-only, not in the reference): start -- and stay -- at this jitter
     multiplier instead of escalating from 1 (:2413-2421), so that the arithmetic after a
@@ -355,7 +433,11 @@ def core(model, hyp, X, y, s2, compute_nlZ, compute_nlZ_grad, force_mult=None):
         sn2, dsn2 = noise(model["noise"], h_noise, X, y, s2, compute_grad=True)
         m, dm = mean(model["mean"], h_mean, X, compute_grad=True)
         m = m.reshape((-1, 1))
-        K, dK = covariance(kernel, h_cov, X, compute_grad=True, degree=degree)
+        if streamed:
+            planes = covariance_planes(kernel, h_cov, X, degree=degree)
+            K = next(planes)
+        else:
+            K, dK = covariance(kernel, h_cov, X, compute_grad=True, degree=degree)
     else:
         sn2 = noise(model["noise"], h_noise, X, y, s2)
         m = np.reshape(mean(model["mean"], h_mean, X), (-1, 1))
@@ -430,8 +512,15 @@ def core(model, hyp, X, y, s2, compute_nlZ, compute_nlZ_grad, force_mult=None):
                 trans=0,
                 check_finite=False,
             ) / sl - np.dot(alpha, alpha.T)
-            for i in range(cov_N):
-                dnlZ[i] = np.sum(np.sum(Q * dK[:, :, i])) / 2
+            if streamed:
+                L = pL = None  # the factor is not needed past Q; K stays alive inside the generator
+                for i, plane in enumerate(planes):
+                    dnlZ[i] = np.sum(np.sum(Q * plane)) / 2  # :2487-2488 on a contiguous (N, N) plane,
+                    del plane  # which is what dK[:, :, i] of the reference's (cov_N, N, N) C array is
+                assert i == cov_N - 1
+            else:
+                for i in range(cov_N):
+                    dnlZ[i] = np.sum(np.sum(Q * dK[:, :, i])) / 2
             if np.isscalar(sn2):
                 tr_Q = np.trace(Q)
                 for i in range(noise_N):
@@ -453,6 +542,16 @@ def core(model, hyp, X, y, s2, compute_nlZ, compute_nlZ_grad, force_mult=None):
         sn2_mult,
         L_chol,
     )
+
+
+def core_streamed(model, hyp, X, y, s2, force_mult=None):
+    """(nlZ, dnlZ) of ``core`` without ever holding the (N, N, cov_N) gradient tensor: K, the Cholesky factor,
+    alpha, nlZ and Q through the same SciPy calls (gaussian_process.py:2415-2417, :2455-2484), then ONE gradient
+    plane at a time (covariance_functions.py:349-363 and its siblings, ``covariance_planes``), each contracted as
+    :2487-2488 does.  Bit-identical to ``core`` wherever ``core`` can run (pinned on every core_cases.npz
+    gradient and on cfg3 sample 0 of fullsize_cases.npz, tests/test_oracle_golden.py); at cfg4 it is the
+    independent fp64 value for the gradient that the reference itself cannot produce in 64 GB."""
+    return core(model, hyp, X, y, s2, 1, 1, force_mult=force_mult, streamed=True)
 
 
 def posteriors(model, hyps, X, y, s2, force_mult=None):

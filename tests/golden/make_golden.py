@@ -19,7 +19,10 @@ Files written next to this script:
                    at full size (N = 2048 / 4096), a few dozen doubles
   fullsize45_cases.npz the same at cfg4 (N = 16384, RQ: nlZ only -- the reference's (N, N, 22) gradient
                    tensor would need 47 GB) and cfg5 (N = 8192, S = 64: samples 0 and 63 with gradient,
-                   7 and 8 nlZ only); run with the target `fullsize45`
+                   7 and 8 nlZ only); run with the target `fullsize45`.  Target `cfg4grad` adds `cfg4_dnlZ` to that
+                   file: ORACLE-DERIVED (oracle.core_streamed, one gradient plane at a time, ~20 GB, ~10 min) because
+                   the reference needs 47 GB here; the script asserts that the streamed oracle's nlZ is the
+                   reference's stored cfg4 nlZ bit for bit before it writes the gradient
   rank1_cases.npz  GP.update with ONE new point (the reference's rank-one path,
                    gaussian_process.py:750-844), high- and low-noise parametrisation
   api_sweep_reference.txt  (not written by this script) the output of tools/api_sweep.py run against the reference:
@@ -525,6 +528,31 @@ def fullsize45_cases():
     np.savez_compressed(os.path.join(HERE, "fullsize45_cases.npz"), **out)
 
 
+def cfg4_gradient():
+    """cfg4's gradient, which the reference cannot form (covariance_functions.py:349-363 materialises a
+    (22, 16384, 16384) tensor = 47 GB before gaussian_process.py:2487-2488 contracts it): the pinned oracle's
+    streamed restatement (bit-identical to the reference on every core fixture and on cfg3 sample 0, see
+    tests/test_oracle_golden.py), cross-checked here on the one number the reference CAN produce at this size."""
+    import time
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import gp_oracle as orc
+
+    path = os.path.join(HERE, "fullsize45_cases.npz")
+    out = dict(np.load(path, allow_pickle=False))
+    X, y, hyp = _bench_problem(4, 16384, 20, "rq", 1)
+    assert np.array_equal(hyp[0], out["cfg4_hyp"][0])
+    model = dict(kernel="rq", degree=0, mean="const", noise=(1, 0, 0))
+    t0 = time.time()
+    nlZ, dnlZ = orc.core_streamed(model, hyp[0], X, y, None)
+    print(f"cfg4 streamed oracle: nlZ={nlZ!r} ({time.time() - t0:.0f} s); reference nlZ={out['cfg4_nlZ'][0]!r}", flush=True)
+    print("dnlZ =", np.array2string(dnlZ, precision=17))
+    assert nlZ == out["cfg4_nlZ"][0], "the streamed oracle's nlZ is not the reference's"
+    out["cfg4_dnlZ"] = dnlZ[None, :]
+    out["cfg4_dnlZ_source"] = np.array("oracle.core_streamed (oracle-derived: the reference needs 47 GB here)")
+    np.savez_compressed(path, **out)
+
+
 def rank1_cases():
     """GP.update(X_new=1 point, y_new) through the reference's rank-one path (:750-844):
     three consecutive appends; posterior fields after the last one, predictions after each."""
@@ -653,6 +681,8 @@ if __name__ == "__main__":
         fullsize_cases()
     if "fullsize45" in which:  # not in the default list: ~10 minutes and ~15 GB of host memory
         fullsize45_cases()
+    if "cfg4grad" in which:  # ~10 minutes, ~20 GB; oracle-derived (see cfg4_gradient)
+        cfg4_gradient()
     if "rank1" in which:
         rank1_cases()
     if "cov" in which:

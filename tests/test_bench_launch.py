@@ -31,6 +31,23 @@ def test_gpus_2_without_a_launcher_starts_two_ranks():
     assert line["config"]["global_samples"] == 16 and line["config"]["samples_per_gpu"] == 8
     assert line["scaling"] == "strong"
     assert len(r.stdout.strip().splitlines()) == 1  # ONE line on stdout
+    assert line["config"]["exchanges_per_step"] == 1.0  # one collective per sharded call (the frame carries the rows)
+    _check_both_splits(line, world=2, S=16, headline="strong")
+
+
+def _check_both_splits(line, world, S, headline):
+    """The record of a multi-rank run carries the OTHER split and the single-GPU yardstick."""
+    cfg = line["config"]
+    other = "weak" if headline == "strong" else "strong"
+    assert other in cfg and headline not in cfg
+    o = cfg[other]
+    S_other = S * world if other == "weak" else S
+    assert o["global_samples"] == S_other and o["value"] > 0 and o["ms_per_step"] > 0
+    assert abs(o["value"] - S_other / (o["ms_per_step"] * 1e-3)) < 1e-6 * o["value"]
+    e = cfg["expected_from_1gpu"]
+    assert e["strong"]["samples"] == -(-S // world) and e["weak"]["samples"] == S
+    for k in ("strong", "weak"):
+        assert e[k]["ms_per_step"] > 0 and e[k]["value_if_no_exchange"] > 0
 
 
 def test_config_split_at_eight_ranks_and_weak_scaling():
@@ -43,6 +60,7 @@ def test_config_split_at_eight_ranks_and_weak_scaling():
     assert r.returncode == 0, r.stderr[-2000:]
     assert line["n_gpus"] == 4 and line["config"]["global_samples"] == 64 and line["config"]["samples_per_gpu"] == 16
     assert line["scaling"] == "weak"
+    _check_both_splits(line, world=4, S=16, headline="weak")
 
 
 def test_a_failing_rank_fails_the_launch():
@@ -80,6 +98,7 @@ def test_two_self_launched_ranks_on_one_gpu_run_the_timed_path():
     assert line["n_gpus"] == 2 and line["config"]["samples_per_gpu"] == 2 and line["config"]["global_samples"] == 4
     assert line["value"] > 0 and line["config"]["exchanges_per_step"] == 1.0
     assert line["config"]["launcher"] == "self" and line["scaling"] == "strong"
+    _check_both_splits(line, world=2, S=4, headline="strong")
     r1, one = _bench("--gpus", "1", "--config", "2", "--samples", "4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
     assert r1.returncode == 0, r1.stderr[-3000:]
     assert one["n_gpus"] == 1 and abs(one["nlz_sample0"] - line["nlz_sample0"]) == 0.0  # same bits sharded or not

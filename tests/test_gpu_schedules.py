@@ -138,10 +138,13 @@ def test_cfg5_full_batch_of_64_against_the_reference(ctx):
 
 
 def test_cfg4_against_the_reference_fp64_and_fp32(ctx):
-    """cfg4, N = 16384, D = 20, rational quadratic.  The reference's value exists for the NLL only (its gradient
-    tensor would be 47 GB): fp64 device NLL within 1e-8 of it, fp32 within 1e-3 (north_star); the fp32 gradient is
-    held against the fp64 DEVICE gradient (the fp64 RQ path is oracle-checked at N = 1408, 1e-8), 1e-3 per
-    component -- relative to the component itself down to 1e-2 of the largest one."""
+    """cfg4, N = 16384, D = 20, rational quadratic.  nlZ against the reference's own value: fp64 within 1e-8, fp32
+    within 1e-3 (north_star).  The GRADIENT against an independent fp64 value as well (round 5): the reference cannot
+    form it (its (22, N, N) tensor is 47 GB), so the fixture is the pinned oracle's streamed restatement -- one plane at
+    a time, bit-identical to the reference wherever the reference can run, and its nlZ at cfg4 IS the reference's
+    (tests/golden/make_golden.py cfg4grad; tests/test_oracle_golden.py).  fp64 device gradient within 1e-8 of the
+    largest component per component (the bar of every full-size test here), fp32 within 1e-3 per component --
+    relative to the component itself down to 1e-2 of the largest one."""
     import bench
 
     g = np.load(GOLD, allow_pickle=False)
@@ -149,6 +152,8 @@ def test_cfg4_against_the_reference_fp64_and_fp32(ctx):
     assert np.allclose([X.sum(), y.sum()], g["cfg4_Xsum"], rtol=1e-13)
     assert np.array_equal(hyp[0], g["cfg4_hyp"][0])
     rn = float(g["cfg4_nlZ"][0])
+    rd = g["cfg4_dnlZ"][0]
+    assert "oracle-derived" in str(g["cfg4_dnlZ_source"]) and rd.shape == hyp[0].shape
     res = {}
     for dt in ("f64", "f32"):
         gp = bench.make_gp(4, dt)
@@ -161,9 +166,11 @@ def test_cfg4_against_the_reference_fp64_and_fp32(ctx):
             e = abs(v - rn) / max(1.0, abs(rn))
             print(f"cfg4 {dt} {what}: nlZ rel err vs the reference {e:.2e}")
             assert e < tol, (dt, what, e)
-    d64, d32 = res["f64"][1], res["f32"][1]
-    per = np.abs(d32 - d64) / np.maximum(np.abs(d64), 1e-2 * np.abs(d64).max())
-    print("cfg4 fp32 gradient vs fp64 device gradient, per component:", np.array2string(per, precision=1))
+    e64 = _rel_grad(res["f64"][1], rd)
+    print(f"cfg4 fp64 gradient vs the streamed fp64 oracle: {e64:.2e}")
+    assert e64 < 1e-8
+    per = np.abs(res["f32"][1] - rd) / np.maximum(np.abs(rd), 1e-2 * np.abs(rd).max())
+    print("cfg4 fp32 gradient vs the streamed fp64 oracle, per component:", np.array2string(per, precision=1))
     assert per.max() < 1e-3
 
 

@@ -72,18 +72,25 @@ def _more_paths(rank, world, S):
     return res
 
 
-def _worker(rank, world, port, q, sizes=(1, 5, 16), extras=True):
+def _worker(rank, world, port, q, sizes=(1, 5, 16), extras=True, backend="gloo"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    dev = rank if backend == "nccl" else 0  # RCCL: one GPU per rank; gloo: every rank on GPU 0
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      GPYREG_AMD_DEVICE="0")
+                      GPYREG_AMD_DEVICE=str(dev), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
     from numpy.linalg import LinAlgError
 
     import bench
     from gpyreg_amd import sharding
 
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        import torch
+
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     out = {}
     try:
         bench.CONFIGS[3] = dict(bench.CONFIGS[3], N=700)
@@ -203,6 +210,36 @@ def test_sharded_gp_equals_unsharded_bitwise_two_ranks_one_gpu():
         assert r["err"] in ("LinAlgError", "ShardError"), r["err"]
         assert r["mismatch"] is True, r["mismatch"]
         assert r["after"]
+
+
+def test_sharded_gp_equals_unsharded_bitwise_two_ranks_two_gpus_rccl():
+    """The same over RCCL with one GPU per rank: needs two devices, so it is skipped on the one-GPU boxes
+    this repository is developed on; the pooled exchange buffers are reused across the ~40 gathers of the worker."""
+    import subprocess
+
+    n = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                       capture_output=True, text=True).stdout.strip()
+    if not n.isdigit() or int(n) < 2:
+        pytest.skip("needs two GPUs (RCCL, one rank per device)")
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, (1, 5, 16), True, "nccl")) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=900) for _ in procs)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        r = res[rank]
+        assert "exception" not in r, r.get("exception")
+        for S in (1, 5, 16):
+            assert all(r[S].values()), (rank, S, sorted(k for k, v in r[S].items() if not v))
+        assert all(r["rank1"].values()) and all(r["paths"].values())
+        assert r["err"] in ("LinAlgError", "ShardError") and r["mismatch"] is True and r["after"]
 
 
 def test_more_ranks_than_samples_three_ranks_one_gpu():

@@ -149,3 +149,46 @@ def test_rank_one_update_bit_exact():
             assert _eq(p.alpha[:, 0], g[tag + "_alpha"][s]) and _eq(p.sW[:, 0], g[tag + "_sW"][s]), name
             assert _eq(np.diag(p.L), g[tag + "_Ldiag"][s]) and _eq(np.asarray(p.L)[:, -1], g[tag + "_Llast_col"][s]), name
             assert _eq(np.asarray(p.L)[-1, :], g[tag + "_Llast_row"][s]), name
+
+
+def test_streamed_core_is_the_core_bit_for_bit(cov_golden, core_golden):
+    """``core_streamed`` (one gradient plane at a time -- the only way to a gradient at cfg4's size) against the
+    reference's own values: every plane of every cov_cases.npz kernel, and nlZ / dnlZ of all 35 core_cases.npz
+    models, with ``np.array_equal``.  Bit-exact, not 1e-13, because the planes are produced by the same SciPy calls
+    on the same operands (only loop-invariant factors are hoisted) and contracted from a contiguous (N, N) array,
+    which is what ``dK[:, :, i]`` of the reference's (cov_N, N, N) C array is."""
+    g = cov_golden
+    for name in g["names"]:
+        tag, kernel, degree, N, D, M = parse_cov_name(name)
+        planes = list(orc.covariance_planes(kernel, g[tag + "_hyp"], g[tag + "_X"], degree=degree))
+        assert _eq(planes[0], g[tag + "_K"]), name
+        dK = g[tag + "_dK"]
+        assert len(planes) == dK.shape[2] + 1
+        for i in range(dK.shape[2]):
+            assert planes[1 + i].flags.c_contiguous and _eq(planes[1 + i], dK[:, :, i]), (name, i)
+    g = core_golden
+    for name in g["names"]:
+        tag, model, N, D, flavour = parse_core_name(name)
+        X, y, hyp = g[tag + "_X"], g[tag + "_y"], g[tag + "_hyp"]
+        s2 = g[tag + "_s2"] if tag + "_s2" in g.files else None
+        for s in range(hyp.shape[0]):
+            nlZ, dnlZ = orc.core_streamed(model, hyp[s], X, y, s2)
+            assert _eq(nlZ, g[tag + "_nlZ"][s]) and _eq(dnlZ, g[tag + "_dnlZ"][s]), name
+
+
+def test_streamed_core_at_cfg3_full_size_and_the_cfg4_fixture():
+    """cfg3 sample 0 at N = 4096 (fullsize_cases.npz: the reference's own nlZ / dnlZ): the streamed oracle gives the
+    same bits (~20 s).  And the provenance of cfg4's gradient fixture: labelled oracle-derived (the reference would
+    need 47 GB), produced by tests/golden/make_golden.py cfg4grad, which asserted that the streamed oracle's nlZ at
+    cfg4 IS the reference's stored nlZ (bit for bit) before it wrote the gradient."""
+    import os
+
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    g = np.load(os.path.join(here, "fullsize_cases.npz"), allow_pickle=False)
+    model, X, y, hyp = orc.synthetic_problem(3, S=16)
+    assert np.array_equal(hyp[0], g["cfg3_hyp"][0])
+    nlZ, dnlZ = orc.core_streamed(model, hyp[0], X, y, None)
+    assert nlZ == g["cfg3_nlZ"][0] and np.array_equal(dnlZ, g["cfg3_dnlZ"][0])
+    g4 = np.load(os.path.join(here, "fullsize45_cases.npz"), allow_pickle=False)
+    assert g4["cfg4_dnlZ"].shape == (1, 24) and np.isfinite(g4["cfg4_dnlZ"]).all()
+    assert "oracle-derived" in str(g4["cfg4_dnlZ_source"])

@@ -157,6 +157,32 @@ def _err_worker(rank, world, port, q):
         rows, _ = sharding.gather_rows(5, 3, lambda lo, hi: (same[lo:hi], np.zeros(hi - lo, bool)),
                                        token=sharding.fingerprint(same))
         res.append(bool(np.array_equal(rows, same)))
+        # (7) a result too wide for the frame (predictions at many points): header-only frame first, rows in a second
+        # gather; an error and a per-sample flag travel there too
+        wide = np.random.default_rng(8).standard_normal((5, 700))
+        rows, bad = sharding.gather_rows(5, 700, lambda lo, hi: (wide[lo:hi], np.arange(lo, hi) == 3),
+                                         token=sharding.fingerprint(wide))
+        res.append(bool(np.array_equal(rows, wide)) and bad.tolist() == [False, False, False, True, False])
+        try:
+            sharding.gather_rows(5, 700, boom)
+            res.append("no error")
+        except sharding.ShardError:
+            res.append("ShardError")
+        # (8) the ranks disagree about WHICH of the two forms applies (rank 0: 3 columns, in the frame; rank 1: 700):
+        # the first collective has the same shape either way, so both learn of it and neither hangs
+        nc = 3 if rank == 0 else 700
+        try:
+            sharding.gather_rows(5, nc, lambda lo, hi: (np.zeros((hi - lo, nc)), np.zeros(hi - lo, bool)))
+            res.append("no error")
+        except sharding.ShardError as e:
+            res.append("different batches" in str(e))
+        # (9) the buffer pool keeps small fixed shapes only and stays inside its budget: many distinct wide
+        # gathers leave nothing behind
+        before = sharding.pool_bytes()
+        for M in range(9000, 9010):
+            w = np.ones((2, M))
+            sharding.gather_rows(2, M, lambda lo, hi, w=w: (w[lo:hi], np.zeros(hi - lo, bool)))
+        res.append(sharding.pool_bytes() == before and sharding.pool_bytes() <= sharding._POOL_BUDGET)
         q.put((rank, res))
     finally:
         dist.destroy_process_group()
@@ -179,7 +205,8 @@ def test_a_failing_shard_raises_on_every_rank_instead_of_hanging():
         assert res[rank][0] == "ShardError"
         assert res[rank][1] == ([0.0, 1.0, 2.0, 3.0, 4.0], [False, False, False, False, True])
         assert res[rank][2] == [7.0]
-        assert res[rank][3:] == [True, True, True]
+        assert res[rank][3:6] == [True, True, True]
+        assert res[rank][6:] == [True, "ShardError", True, True]
 
 
 def _many_worker(rank, world, port, q):
