@@ -84,6 +84,8 @@ SIGNATURES = {
     ),
     "gpc_debug_leaf": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp, _ip]),
     "gpc_debug_factor": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip]),
+    "gpc_debug_workspace_hash": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "gpc_debug_dag": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip, _dp, _ip, C.c_int, C.c_int]),
 }
 
 # int (*gpc_dk_plane_fn)(void* user, int sample, int p, double* plane)
@@ -118,7 +120,14 @@ def _f64(a):
 
 
 def _ptr(a):
-    return None if a is None else a.ctypes.data
+    """The bare address of an array for a ``c_void_p`` argument.  KEEP-ALIVE INVARIANT: unlike ``ctypes.data_as`` the
+    integer holds no reference to the array, and the call it is passed to releases the GIL -- so ``a`` must be bound to
+    a name that outlives the call (every call site converts into a local first: ``x = _f64(x)`` ... ``_ptr(x)``).
+    Never ``_ptr(_f64(x))`` or ``_ptr(x.ravel())`` inline: the temporary would be freed before the library reads it."""
+    if a is None:
+        return None
+    assert isinstance(a, np.ndarray) and a.flags.c_contiguous, "pass a named, C-contiguous ndarray (see docstring)"
+    return a.ctypes.data
 
 
 def _serial(method):

@@ -23,6 +23,7 @@
 #include "gemm.h"
 #include "leaf.h"
 #include "plan.h"
+#include "dag.h"
 
 using namespace gpc;
 
@@ -132,10 +133,19 @@ __device__ __forceinline__ void xfer_body_noxs(const XferDesc& d, unsigned long 
   if (d.r_out || d.dvec_out) {
     const unsigned long long tot = (unsigned long long)d.fnpad * d.fcnt;
     for (unsigned long long q = gt; q < tot; q += stride) {
-      const unsigned long long b = q / d.fnpad;
-      const int i = (int)(q - b * d.fnpad);
-      if (d.r_out) d.r_out[q] = i < d.fn ? d.y[i] - d.m0[b] : 0.0;
-      if (d.dvec_out) d.dvec_out[q] = i < d.fn ? d.dval[b] : 1.0;
+      // the sample index is the same for the 64 lanes of a wave (gt is wave-contiguous from a multiple of 64, stride
+      // a multiple of 256, fnpad a multiple of 128): the two per-sample constants are read from the mapped host block
+      // ONCE per wave through the scalar unit, not once per element (S * npad uncached PCIe reads)
+      const int b = __builtin_amdgcn_readfirstlane((int)(q / d.fnpad));
+      const int i = (int)(q - (unsigned long long)b * d.fnpad);
+      if (d.r_out) {
+        const double m0b = d.m0[b];
+        d.r_out[q] = i < d.fn ? d.y[i] - m0b : 0.0;
+      }
+      if (d.dvec_out) {
+        const double dvb = d.dval[b];
+        d.dvec_out[q] = i < d.fn ? dvb : 1.0;
+      }
     }
   }
 }
@@ -504,6 +514,26 @@ struct gpc_ctx {
   double start_mult = 1.0;
   unsigned append_fail_mask = 0;
   int retry_runs = 0;  // device pipelines spent on jitter retries by the last call (one per level)
+  // ---- tile-level dataflow (dag.h).  Option "dag": 0 off, 1 wherever the plan supports it, -1 automatic (by what was
+  // measured to win).  The arithmetic is that of the stream-ordered schedule bit for bit, so the choice may follow the
+  // batch size.
+  int dag = 0;
+  int dag_small_tiles = 40;  // launches with fewer 128-tiles per sample than this become 64-tile tasks (urgent ring)
+  int dag_lauum = 1;         // W^T W inside the graph (its tiles fill the CUs other samples' chains leave idle)
+  int dag_leaf_blocks = 0;   // leaf servers; 0: min(samples, 8)
+  int dag_timeout_ms = 2000; // a workgroup that finds nothing to do for this long aborts the graph
+  int dag_runs = 0, dag_aborts = 0;  // statistics (gpc_get_option "dag_runs" / "dag_aborts")
+  bool dag_used = false;     // the pipeline in flight runs a graph: its abort word rides back with the results
+  struct DagEntry {
+    unsigned long long key = 0;
+    gpc::DagPlan plan;  // (host vectors are released after the upload; the counts stay)
+    DevBuf tasks, succ, launches_rel;
+    unsigned long long last_use = 0;
+  };
+  std::vector<DagEntry> dag_cache;
+  unsigned long long dag_clock = 0;
+  DevBuf dag_pending, dag_slots, dag_ctl, dag_launches;
+  DevBuf rsv_tbl1;  // cu_reserve_bail table with ONE CU per XCD (the leaf servers' room)
 };
 
 struct gpc_post {
@@ -609,6 +639,18 @@ int build_reserve_table(gpc_ctx* c) {
   }
   HIPCHK(c, c->rsv_tbl.ensure(sizeof tbl));
   HIPCHK(c, hipMemcpyAsync(c->rsv_tbl.p, tbl, sizeof tbl, hipMemcpyHostToDevice, c->st));
+  // the dataflow schedule (dag.h) keeps ONE CU per XCD free of GEMM workgroups for its leaf servers: the
+  // highest-numbered CU of the first shader engine seen in each XCD
+  unsigned short tbl1[64] = {};
+  for (int x = 0; x < 8; ++x)
+    for (int se = 0; se < 8; ++se) {
+      const unsigned m = c->cu_seen[x * 8 + se];
+      if (!m) continue;
+      tbl1[x * 8 + se] = (unsigned short)(1u << (31 - __builtin_clz(m)));
+      break;
+    }
+  HIPCHK(c, c->rsv_tbl1.ensure(sizeof tbl1));
+  HIPCHK(c, hipMemcpyAsync(c->rsv_tbl1.p, tbl1, sizeof tbl1, hipMemcpyHostToDevice, c->st));
   HIPCHK(c, hipStreamSynchronize(c->st));
   return 0;
 }
@@ -907,7 +949,20 @@ struct Pipe {
     const int nll_blk = c->nll_block >= 0 ? c->nll_block
                                           : (npad >= 2048 ? 512 : 0);
     const bool nll_blocked = !use_rl && mode == MODE_NLL && nll_blk >= TILE && npad > nll_blk;
-    if (use_rl) {
+    bool dag_done = false, dag_has_lauum = false;
+    if (nll_blocked) F.nll_block = nll_blk;  // (the blocked forward solve below reads it, whichever schedule factors)
+    if (use_dag && !use_rl) {
+      int rc = dag_section(st, gidx, F, nll_blocked ? nll_blk : 0, full_inv, dag_has_lauum);
+      if (rc < 0) return rc;
+      dag_done = rc == 0;  // (rc > 0: the plan is not one the graph executes -- the stream-ordered schedule below)
+      if (dag_done && getenv("GPC_DAG_SYNC")) {
+        (void)hipStreamSynchronize(c->sst[gidx]);
+        (void)hipStreamSynchronize(st);
+      }
+    }
+    if (dag_done) {
+      // (the factorization -- and W^T W when it is part of the graph -- has been issued)
+    } else if (use_rl) {
       F.rl_panel = c->rl_panel;
       F.rl_lookahead = (double)n * std::pow((double)npad / 4096.0, 3.0) <= (double)c->rl_ahead_max;
       F.potrf_rl();
@@ -925,7 +980,7 @@ struct Pipe {
     // needs alpha.  (Eager one- or multi-group pipelines; a captured graph keeps the serial order.)
     // (fp64 only: the fp32 GEMM uses 249 VGPRs, two of its blocks leave no register for anything else)
     const bool solves_beside_lauum = mode == MODE_GRAD && !c->capturing && !kmode() && c->solves_beside_lauum &&
-                                     sizeof(T) == 8 && npad >= 2048 && gpc::g_persist_spare >= 0;
+                                     sizeof(T) == 8 && npad >= 2048 && gpc::g_persist_spare >= 0 && !dag_has_lauum;
     auto solves = [&](hipStream_t sx) -> int {
       const hipStream_t keep = F.st;
       F.st = sx;
@@ -967,11 +1022,13 @@ struct Pipe {
         if (int rc = solves(sx)) return rc;
         HIPCHK(c, hipEventRecord(ev_solved, sx));
       }
-      if (!c->capturing) HIPCHK(c, hipEventRecord(c->ev_l0[gidx], st));
-      F.lauum(Tc, sM);
-      if (!c->capturing) {
-        HIPCHK(c, hipEventRecord(c->ev_l1[gidx], st));
-        lauum_n[gidx] = n;
+      if (!dag_has_lauum) {
+        if (!c->capturing) HIPCHK(c, hipEventRecord(c->ev_l0[gidx], st));
+        F.lauum(Tc, sM);
+        if (!c->capturing) {
+          HIPCHK(c, hipEventRecord(c->ev_l1[gidx], st));
+          lauum_n[gidx] = n;
+        }
       }
     }
     HIPCHK(c, F.err);
@@ -1021,6 +1078,174 @@ struct Pipe {
     return 0;
   }
 
+  // ---- tile-level dataflow (dag.h) ----------------------------------------------------------------------------
+  bool use_dag = false;  // run(): this pipeline's factorization goes through the task graph
+  // "dag" = -1: where the graph was measured to win
+  bool dag_auto(int cnt, int npad) const { return false; }
+
+  // The graph of (npad, plan variant): recorded from plan.h with placeholder buffer addresses, cut into tile tasks,
+  // uploaded once and kept.  Returns nullptr when the plan holds something the graph does not execute.
+  gpc_ctx::DagEntry* dag_plan(int nll_blk, bool full_inv, bool with_lauum, double* flops1) {
+    Batch& b = *B;
+    const int npad = b.npad;
+    const unsigned long long key = (unsigned long long)npad | ((unsigned long long)sizeof(T) << 20) |
+                                   ((unsigned long long)nll_blk << 24) | ((unsigned long long)full_inv << 40) |
+                                   ((unsigned long long)with_lauum << 41) | ((unsigned long long)mode << 42) |
+                                   ((unsigned long long)c->dag_small_tiles << 44);
+    for (auto& e : c->dag_cache)
+      if (e.key == key) {
+        e.last_use = ++c->dag_clock;
+        *flops1 = e.plan.work_us;  // (work_us is reused to carry the algorithmic flops of one sample, see below)
+        return e.plan.ntasks > 0 ? &e : nullptr;
+      }
+    PlanRecorder rec;
+    Factor<T> F;
+    F.rec = &rec;
+    F.st = nullptr;
+    F.batch = 1;
+    F.npad = npad;
+    F.A = static_cast<T*>(const_cast<void*>(dag_fake_base(0)));
+    F.W = static_cast<T*>(const_cast<void*>(dag_fake_base(1)));
+    F.Tm = static_cast<T*>(const_cast<void*>(dag_fake_base(2)));
+    F.sA = F.sW = F.sT = sM;
+    F.nvalid = b.N;
+    F.dual_launch = false;
+    if (nll_blk > 0) {
+      F.nll_block = nll_blk;
+      F.potrf_nll(0, npad);
+    } else {
+      F.potrf_inv(0, npad, full_inv, false);
+    }
+    if (with_lauum) F.lauum(F.Tm, sM);
+    if (c->dag_cache.size() >= 8) {  // least recently used entry goes
+      size_t old = 0;
+      for (size_t i = 1; i < c->dag_cache.size(); ++i)
+        if (c->dag_cache[i].last_use < c->dag_cache[old].last_use) old = i;
+      c->dag_cache[old].tasks.release();
+      c->dag_cache[old].succ.release();
+      c->dag_cache[old].launches_rel.release();
+      c->dag_cache.erase(c->dag_cache.begin() + old);
+    }
+    c->dag_cache.emplace_back();
+    gpc_ctx::DagEntry& e = c->dag_cache.back();
+    e.key = key;
+    e.last_use = ++c->dag_clock;
+    const void* bases[3] = {dag_fake_base(0), dag_fake_base(1), dag_fake_base(2)};
+    DagPlan& P = e.plan;
+    if (!build_dag(rec, bases, npad, sizeof(T), c->dag_small_tiles, P)) {
+      P = DagPlan{};
+      P.work_us = F.flops;
+      *flops1 = F.flops;
+      return nullptr;
+    }
+    if (getenv("GPC_DAG_LOG"))
+      fprintf(stderr, "[gpcore] dag npad=%d nll_blk=%d lauum=%d: %d tasks (%d leaves, %d x 64, %d x 128), %lld edges, %zu launches; "
+                      "model: critical path %.0f us, work %.0f CU-us\n", npad, nll_blk, (int)with_lauum, P.ntasks, P.nleaf, P.n64, P.n128,
+              P.nedges, P.launches.size(), P.crit_us, P.work_us);
+    auto put = [&](DevBuf& d, const void* src, size_t n) -> hipError_t {
+      hipError_t er = d.ensure(std::max<size_t>(n, 16));
+      if (er != hipSuccess) return er;
+      return hipMemcpy(d.p, src, n, hipMemcpyHostToDevice);
+    };
+    if (put(e.tasks, P.tasks.data(), P.tasks.size() * sizeof(DagTask)) != hipSuccess ||
+        put(e.succ, P.succ.data(), P.succ.size() * sizeof(int)) != hipSuccess ||
+        put(e.launches_rel, P.launches.data(), P.launches.size() * sizeof(GemmArgs)) != hipSuccess) {
+      c->dag_cache.pop_back();
+      return nullptr;
+    }
+    P.work_us = F.flops;  // from here on: algorithmic flops of one sample (tile-exact, as plan.h counts them)
+    std::vector<DagTask>().swap(P.tasks);
+    std::vector<int>().swap(P.succ);
+    *flops1 = F.flops;
+    return &e;
+  }
+
+  // Issues the graph for the n samples of F.  0: issued; > 0: not applicable (the caller falls back); < 0: error.
+  int dag_section(hipStream_t st, int gidx, Factor<T>& F, int nll_blk, bool full_inv, bool& has_lauum) {
+    const int n = F.batch, npad = F.npad;
+    const bool with_lauum = mode == MODE_GRAD && c->dag_lauum != 0;
+    double flops1 = 0;
+    gpc_ctx::DagEntry* e = dag_plan(nll_blk, full_inv, with_lauum, &flops1);
+    if (!e) return 1;
+    const DagPlan& P = e->plan;
+    const int nlaunch = (int)P.launches.size();
+    // ring storage: urgent | NQ bulk rings | leaf
+    DagDev d{};
+    int off = 0;
+    d.nteams = std::min(n, (int)NQ);
+    for (int q = 0; q < NQ; ++q) {  // team q holds the samples q, q + nteams, ...
+      const int members = q < d.nteams ? (n - q + d.nteams - 1) / d.nteams : 0;
+      d.ring_base[DAG_RING_URGENT + q] = off;
+      off += members * P.n64;
+      d.ring_base[DAG_RING_BULK0 + q] = off;
+      off += members * P.n128;
+    }
+    d.ring_base[DAG_RING_LEAF] = off;
+    off += n * P.nleaf;
+    HIPCHK(c, c->dag_slots.ensure((size_t)std::max(off, 4) * sizeof(int)));
+    HIPCHK(c, c->dag_pending.ensure((size_t)n * P.ntasks * sizeof(int)));
+    HIPCHK(c, c->dag_ctl.ensure(sizeof(DagCtl)));
+    HIPCHK(c, c->dag_launches.ensure((size_t)std::max(nlaunch, 1) * sizeof(GemmArgs)));
+    d.tasks = e->tasks.template as<DagTask>();
+    d.succ = e->succ.template as<int>();
+    d.launches_rel = e->launches_rel.template as<GemmArgs>();
+    d.launches_w = c->dag_launches.template as<GemmArgs>();
+    d.launches = d.launches_w;
+    d.nlaunch = nlaunch;
+    d.base[0] = F.A;
+    d.base[1] = F.W;
+    d.base[2] = F.Tm;
+    d.pending = c->dag_pending.template as<int>();
+    d.slots = c->dag_slots.template as<int>();
+    d.ctl = c->dag_ctl.template as<DagCtl>();
+    d.ntasks = P.ntasks;
+    d.S = n;
+    d.A = F.A;
+    d.W = F.W;
+    d.sA = F.sA;
+    d.sW = F.sW;
+    d.npad = npad;
+    d.nvalid = F.nvalid;
+    d.logdet = F.logdet;
+    d.info = F.info;
+    d.rsv = c->rsv_tbl1.template as<unsigned short>();
+    d.timeout_ticks = (long long)c->dag_timeout_ms * 100000ll;  // wall_clock64: 100 MHz
+    HIPCHK(c, hipMemsetAsync(d.slots, 0, (size_t)off * sizeof(int), st));
+    HIPCHK(c, hipMemsetAsync(d.ctl, 0, sizeof(DagCtl), st));
+    const long long items = (long long)n * P.ntasks;
+    hipLaunchKernelGGL(dag_init_kernel, dim3((unsigned)std::min<long long>(1024, (items + 255) / 256)), dim3(256), 0, st, d);
+    // The leaf servers run on the pipeline's own stream (created with the greatest priority: they are the latency-bound
+    // chain), the GEMM workers on the side stream (least priority, like every chip-filling side launch of plan.h).
+    hipStream_t sd = c->sst[gidx];
+    hipEvent_t ev_fork = c->dev_ev[gidx][0], ev_join = c->dev_ev[gidx][1];
+    HIPCHK(c, hipEventRecord(ev_fork, st));
+    HIPCHK(c, hipStreamWaitEvent(sd, ev_fork, 0));
+    if (mode == MODE_GRAD && with_lauum) HIPCHK(c, hipEventRecord(c->ev_l0[gidx], sd));
+    // EXACTLY two workgroups per CU (74 KB of LDS each: the grid fills every CU by pigeonhole); the two that land on the
+    // reserved CU of each XCD return at once and leave it empty for a leaf server.  No surplus: workgroups that cannot
+    // be placed stay pending in the dispatcher, and a dispatch with pending workgroups kept the YOUNGER leaf launch from
+    // starting at all (measured: an oversized grid drained only through the shader engine that holds the reserved CU,
+    // 24 of 80 surplus workgroups; the leaf servers started 12 us after the workers had given up).
+    hipLaunchKernelGGL((dag_worker_kernel<T>), dim3(gpc::g_block_slots), dim3(256), 0, sd, d);
+    if (mode == MODE_GRAD && with_lauum) {
+      HIPCHK(c, hipEventRecord(c->ev_l1[gidx], sd));
+      lauum_n[gidx] = -n;  // negative: the timed launch is the whole graph (run() prices it as S N^3 flops)
+    }
+    HIPCHK(c, hipEventRecord(ev_join, sd));
+    // (test hook: dag_leaf_blocks < 0 starts NO leaf server -- the graph stalls at its first leaf, the workers' bounded
+    // waits run out, the graph aborts and run() falls back to the stream-ordered schedule)
+    const int nl = std::max(1, std::min(c->dag_leaf_blocks > 0 ? c->dag_leaf_blocks : std::min(n, 8), 8));
+    if (c->dag_leaf_blocks >= 0)
+      hipLaunchKernelGGL((dag_leaf_kernel<T>), dim3(nl), dim3(256), 0, st, d, gpc::g_leaf_fault);
+    HIPCHK(c, hipStreamWaitEvent(st, ev_join, 0));
+    HIPCHK(c, hipGetLastError());
+    F.flops += flops1 * n;
+    F.launches += 2;
+    has_lauum = with_lauum;
+    c->dag_used = true;
+    ++c->dag_runs;
+    return 0;
+  }
   // device_section through a cached launch graph (one sample group, main stream)
   int graph_section(int cnt) {
     Batch& b = *B;
@@ -1121,6 +1346,7 @@ struct Pipe {
   bool use_rl = false;  // plan.h: right-looking panels with look-ahead for this pipeline
   bool stable = false;  // plan.h: refined panel solves (jitter retries; gpc_set_option "stable")
   bool prescaled = false;  // the transfer kernel of this chunk has written the scaled inputs (run())
+  std::vector<double> r_expanded;  // run(): r = y - m0 formed on the host when no pinned block was to be had
   int lauum_n[gpc_ctx::MAXG + 1] = {};
 
   // The pipeline of a chunk whose matrices are single 128 x 128 leaves (see run()).  A, W, Tm point at the chunk's slot.
@@ -1201,6 +1427,9 @@ struct Pipe {
     if (land) memcpy(hscal.data(), land, scal_bytes);
     memcpy(&logdet[s0], hscal.data(), (size_t)cnt * 8);
     memcpy(&quad[s0], hscal.data() + cnt, (size_t)cnt * 8);
+    if (getenv("GPC_SCALAR_LOG"))
+      for (int i = 0; i < cnt; ++i)
+        fprintf(stderr, "[gpcore] sample %d dag=%d logdet %.17g quad %.17g\n", s0 + i, (int)c->dag_used, logdet[s0 + i], quad[s0 + i]);
     const int* hinfo = reinterpret_cast<const int*>(hscal.data() + 2 * (size_t)cnt);
     hc.lap("d2h+sync");
     for (int i = 0; i < cnt; ++i) b.info[s0 + i] = hinfo[i];
@@ -1222,7 +1451,23 @@ struct Pipe {
   // The chunk is split into sample groups on separate HIP streams: the latency-bound
   // phases of one group (leaves, deep recursion levels) run beside the throughput-bound
   // GEMMs of the other.
+  // One pipeline for the samples [s0, s0 + cnt).  A dataflow graph that aborted (a bounded wait ran out: never
+  // expected) is not an error of the call: the batch goes again on the stream-ordered schedule.
+  static constexpr int DAG_RETRY = 77;
+  bool dag_off_once = false;
   int run(int s0, int cnt, int slot) {
+    int rc = run_once(s0, cnt, slot);
+    if (rc == DAG_RETRY) {
+      ++c->dag_aborts;
+      if (getenv("GPC_DAG_LOG")) fprintf(stderr, "[gpcore] dataflow graph aborted; re-running on the stream-ordered schedule\n");
+      dag_off_once = true;
+      rc = run_once(s0, cnt, slot);
+      dag_off_once = false;
+    }
+    return rc;
+  }
+
+  int run_once(int s0, int cnt, int slot) {
     Batch& b = *B;
     const int npad = b.npad, N = b.N, D = b.D;
     hipStream_t st = c->st;
@@ -1328,7 +1573,12 @@ struct Pipe {
         fu.r_out = c->rvec.as<double>();
         fill_r = true;
       } else {
-        FAIL(c, "out of pinned host memory");
+        // no pinned block for the per-sample constants: r = y - m0 (the same subtraction, so the same bits) is expanded
+        // here and travels like every other staged input, with its plain-copy fallback
+        r_expanded.assign((size_t)cnt * npad, 0.0);
+        for (int i = 0; i < cnt; ++i)
+          for (int k = 0; k < N; ++k) r_expanded[(size_t)i * npad + k] = b.y[k] - b.m[s0 + i];
+        up(c->rvec.p, r_expanded.data(), cnt * vb);
       }
     } else {
       // r = y - m is read from its staged copy by the kernel that needs it (leaf_solve_kernel, at its start: the round
@@ -1394,7 +1644,19 @@ struct Pipe {
     // Launch graphs: every one-group pipeline whose schedule lives on ONE stream (the deferred products and the split
     // build fork to side streams with CU-reserving launches and stay eager).  Round 3: up to npad = 4096 (round 2
     // stopped at 1024) -- N = 2000: 1.171 -> 1.137 ms, N = 4096: 3.03 -> 2.97 ms per single NLL+grad evaluation.
-    if (groups == 1 && defer_node == 0 && !use_rl && c->graph_max_npad > 0 && npad <= c->graph_max_npad && !kmode()) {
+    // Tile-level dataflow (dag.h) instead of one launch per product: same tile arithmetic, so the choice may follow
+    // the batch size.  One sample group, no deferred launches (the graph overlaps them by itself), eager.
+    use_dag = false;
+    c->dag_used = false;
+    if (c->dag != 0 && !dag_off_once && !kmode() && !(stable || c->stable) && mode != MODE_POST && !use_rl &&
+        gpc::g_leaf_version == 5 && c->cu_map_ok && npad >= 2 * TILE && c->dag_aborts < 3) {
+      use_dag = c->dag > 0 || dag_auto(cnt, npad);
+      if (use_dag) {
+        groups = 1;
+        defer_node = 0;
+      }
+    }
+    if (groups == 1 && defer_node == 0 && !use_rl && !use_dag && c->graph_max_npad > 0 && npad <= c->graph_max_npad && !kmode()) {
       int rc = graph_section(cnt);
       if (rc) return rc;
     } else if (groups == 1) {
@@ -1432,11 +1694,42 @@ struct Pipe {
       if (noise_N > 0 && b.vec_noise)
         HIPCHK(c, c->pin.gather(&ng[(size_t)s0 * noise_N], c->ng.p, (size_t)cnt * noise_N * 8, st));
     }
+    int dag_words[2] = {0, 0};  // [abort, leaf servers started] of the graph, when one ran
+    if (c->dag_used)
+      HIPCHK(c, c->pin.gather(dag_words, reinterpret_cast<char*>(c->dag_ctl.p) + offsetof(DagCtl, abort), 8, st));
     HIPCHK(c, c->pin.flush_down(st));
     HIPCHK(c, hipStreamSynchronize(st));
     c->pin.finish();
+    if (c->dag_used && getenv("GPC_DAG_STATS")) {
+      DagCtl h;
+      (void)hipMemcpy(&h, c->dag_ctl.p, sizeof h, hipMemcpyDeviceToHost);
+      const double w = std::max<double>(1.0, (double)h.n_workers), k = 1e-3 / 100.0;  // clock64: 100 MHz constant clock -> us
+      fprintf(stderr, "[gpcore] dag stats: %llu workers, %llu tasks (%llu kept); per worker us: life %.0f = pop %.0f + acquire %.0f + run %.0f + complete %.0f; "
+                      "per task us: pop %.2f acquire %.2f run %.2f complete %.2f\n", h.n_workers, h.n_tasks, h.n_kept, h.t_life / w * k * 1e3,
+              h.t_pop / w * k * 1e3, h.t_acq / w * k * 1e3, h.t_exec / w * k * 1e3, h.t_done / w * k * 1e3,
+              h.t_pop * k * 1e3 / std::max<double>(1.0, (double)h.n_tasks), h.t_acq * k * 1e3 / std::max<double>(1.0, (double)h.n_tasks),
+              h.t_exec * k * 1e3 / std::max<double>(1.0, (double)h.n_tasks), h.t_done * k * 1e3 / std::max<double>(1.0, (double)h.n_tasks));
+    }
+    if (c->dag_used && dag_words[0] != 0) {
+      if (getenv("GPC_DAG_LOG")) {
+        DagCtl h;
+        (void)hipMemcpy(&h, c->dag_ctl.p, sizeof h, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[gpcore] dag abort code %d, leaf servers started %d, remaining %d, reserve started %d survivors %d; rings (head/tail):",
+                h.abort, h.leaf_alive, h.remaining, h.reserve_ctr[CTR_STARTED], h.reserve_ctr[CTR_SURVIVORS]);
+        for (int r = 0; r < DAG_NRINGS; ++r) fprintf(stderr, " %d/%d", *h.ring[r].head(), *h.ring[r].tail());
+        fprintf(stderr, "; us: leaf server start %d, first worker start %d, first worker exit %d; leaf servers saw (head tail remaining | exit us):",
+                h.pad[0], h.pad[1], h.pad[2]);
+        for (int q = 0; q < 4; ++q) fprintf(stderr, " [%d %d %d | %d]", h.pad[4 + 4 * q], h.pad[5 + 4 * q], h.pad[6 + 4 * q], h.pad[7 + 4 * q]);
+        fprintf(stderr, "\n");
+      }
+      for (int g = 0; g <= gpc_ctx::MAXG; ++g) lauum_n[g] = 0;
+      return DAG_RETRY;
+    }
     memcpy(&logdet[s0], hscal.data(), (size_t)cnt * 8);
     memcpy(&quad[s0], hscal.data() + cnt, (size_t)cnt * 8);
+    if (getenv("GPC_SCALAR_LOG"))
+      for (int i = 0; i < cnt; ++i)
+        fprintf(stderr, "[gpcore] sample %d dag=%d logdet %.17g quad %.17g\n", s0 + i, (int)c->dag_used, logdet[s0 + i], quad[s0 + i]);
     memcpy(hinfo.data(), hscal.data() + 2 * (size_t)cnt, (size_t)cnt * sizeof(int));
     hc.lap("d2h+sync");
     for (int i = 0; i < cnt; ++i) b.info[s0 + i] = hinfo[i];
@@ -1463,12 +1756,15 @@ struct Pipe {
     c->ms_factor += t12;
     if (mode == MODE_GRAD) {  // the dominant single kernel: the lauum launch of each group
       for (int g = 0; g <= gpc_ctx::MAXG; ++g)
-        if (lauum_n[g] > 0) {
+        if (lauum_n[g] != 0) {
           float t = 0;
           (void)hipEventElapsedTime(&t, c->ev_l0[g], c->ev_l1[g]);
           if (t > c->ms_lauum) {
             c->ms_lauum = t;
-            c->flops_lauum = (double)lauum_n[g] * (double)b.N * b.N * b.N / 3.0;
+            // (negative count: the timed launch is the dataflow graph -- factorization, inverse and W^T W of every
+            // sample: S N^3 algorithmic flops)
+            c->flops_lauum = lauum_n[g] > 0 ? (double)lauum_n[g] * (double)b.N * b.N * b.N / 3.0
+                                            : (double)(-lauum_n[g]) * (double)b.N * b.N * b.N;
           }
           lauum_n[g] = 0;
         }
@@ -2365,6 +2661,28 @@ int append_impl(gpc_post* po, const double* m_star, const double* sn2_star, doub
 // =====================================================================================
 // C ABI
 // =====================================================================================
+namespace {
+template <typename T>
+__global__ void tile_hash_kernel(const T* __restrict__ M, int npad, unsigned long long* __restrict__ out) {
+  const int ti = blockIdx.y, tj = blockIdx.x;
+  unsigned long long h = 0;
+  for (int e = threadIdx.x; e < TILE * TILE; e += 256) {
+    const T v = M[(size_t)(ti * TILE + e / TILE) * npad + tj * TILE + e % TILE];
+    unsigned long long b = 0;
+    memcpy(&b, &v, sizeof(T));
+    h += b * (unsigned long long)(2 * e + 1);
+  }
+  __shared__ unsigned long long sh[256];
+  sh[threadIdx.x] = h;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[ti * gridDim.x + tj] = sh[0];
+}
+}  // namespace
+
 extern "C" {
 
 int gpc_create(int device, gpc_ctx** out) {
@@ -2946,6 +3264,16 @@ int gpc_set_option(gpc_ctx* c, const char* name, int value) {
     c->stable = value != 0;
   else if (n == "small_path")  // 0: problems of one leaf take the general pipeline too (A/B and cross-checks)
     c->small_path = value != 0;
+  else if (n == "dag")
+    c->dag = value;
+  else if (n == "dag_small_tiles") {
+    c->dag_small_tiles = value;
+  } else if (n == "dag_lauum")
+    c->dag_lauum = value;
+  else if (n == "dag_leaf_blocks")
+    c->dag_leaf_blocks = value;
+  else if (n == "dag_timeout_ms")
+    c->dag_timeout_ms = value;
   else if (n == "check_queues")  // debug: verify the tile queues of persistent launches after every pipeline
     c->check_queues = value != 0;
   else if (n == "start_mult_log10")  // test hook: first jitter multiplier 10^value
@@ -2974,6 +3302,13 @@ int gpc_get_option(gpc_ctx* c, const char* name, int* value) {
   else if (n == "stable") *value = c->stable;
   else if (n == "small_path") *value = c->small_path;
   else if (n == "check_queues") *value = c->check_queues;
+  else if (n == "dag") *value = c->dag;
+  else if (n == "dag_small_tiles") *value = c->dag_small_tiles;
+  else if (n == "dag_lauum") *value = c->dag_lauum;
+  else if (n == "dag_leaf_blocks") *value = c->dag_leaf_blocks;
+  else if (n == "dag_timeout_ms") *value = c->dag_timeout_ms;
+  else if (n == "dag_runs") *value = c->dag_runs;
+  else if (n == "dag_aborts") *value = c->dag_aborts;
   else FAIL(c, "gpc_get_option: unknown option");
   return 0;
 }
@@ -3093,6 +3428,89 @@ int gpc_debug_factor(gpc_ctx* c, int dtype, int n, const double* A, double* L, d
   HIPCHK(c, hipSetDevice(c->device));
   return dtype == GPC_F64 ? debug_factor_impl<double>(c, n, A, L, W, Ainv, logdet, info)
                           : debug_factor_impl<float>(c, n, A, L, W, Ainv, logdet, info);
+}
+
+// Debug: a 64-bit hash (sum of the bit patterns, wrapping) of every 128 x 128 tile of one workspace matrix of the LAST call
+// (which: 0 = A, 1 = W, 2 = T; `sample` = position in the last chunk) -- to find the tile where two schedules differ.
+int gpc_debug_workspace_hash(gpc_ctx* c, int dtype, int which, int sample, unsigned long long* out) {
+  if (!c || !out || which < 0 || which > 2) return -2;
+  HIPCHK(c, hipSetDevice(c->device));
+  const int npad = c->npad, nt = npad / TILE;
+  DevBuf& m = which == 0 ? c->mA : (which == 1 ? c->mW : c->mT);
+  const size_t esz = dtype == GPC_F64 ? 8 : 4;
+  if (m.bytes < (size_t)(sample + 1) * npad * npad * esz) FAIL(c, "gpc_debug_workspace_hash: no such sample in the workspace");
+  HIPCHK(c, c->dbg3.ensure((size_t)nt * nt * 8));
+  if (dtype == GPC_F64)
+    hipLaunchKernelGGL((tile_hash_kernel<double>), dim3(nt, nt), dim3(256), 0, c->st, m.as<double>() + (size_t)sample * npad * npad, npad,
+                       c->dbg3.as<unsigned long long>());
+  else
+    hipLaunchKernelGGL((tile_hash_kernel<float>), dim3(nt, nt), dim3(256), 0, c->st, m.as<float>() + (size_t)sample * npad * npad, npad,
+                       c->dbg3.as<unsigned long long>());
+  HIPCHK(c, hipMemcpyAsync(out, c->dbg3.p, (size_t)nt * nt * 8, hipMemcpyDeviceToHost, c->st));
+  HIPCHK(c, hipStreamSynchronize(c->st));
+  return 0;
+}
+
+// Host-only (no device call): the tile-task graph dag.h derives for a factorization of an npad x npad matrix.
+int gpc_debug_dag(int npad, int plan, int nll_blk, int small_tiles, int* counts, int* tasks_out, double* alpha_out,
+                  int* succ_out, int cap_tasks, int cap_edges) {
+  if (npad <= 0 || npad % TILE || !counts) return -2;
+  PlanRecorder rec;
+  Factor<double> F;
+  F.rec = &rec;
+  F.st = nullptr;
+  F.batch = 1;
+  F.npad = npad;
+  F.A = static_cast<double*>(const_cast<void*>(dag_fake_base(0)));
+  F.W = static_cast<double*>(const_cast<void*>(dag_fake_base(1)));
+  F.Tm = static_cast<double*>(const_cast<void*>(dag_fake_base(2)));
+  F.sA = F.sW = F.sT = (long long)npad * npad;
+  F.dual_launch = false;
+  if (plan == 0) {  // NLL only
+    if (nll_blk > 0) {
+      F.nll_block = nll_blk;
+      F.potrf_nll(0, npad);
+    } else {
+      F.potrf_inv(0, npad, false, false);
+    }
+  } else {
+    F.potrf_inv(0, npad, true, false);
+    if (plan == 1) F.lauum(F.Tm, F.sT);
+  }
+  const void* bases[3] = {dag_fake_base(0), dag_fake_base(1), dag_fake_base(2)};
+  DagPlan P;
+  if (!build_dag(rec, bases, npad, sizeof(double), small_tiles, P, true)) return -1;
+  counts[0] = P.ntasks;
+  counts[1] = (int)P.nedges;
+  counts[2] = (int)P.launches.size();
+  counts[3] = P.nleaf;
+  if (!tasks_out) return 0;
+  if (cap_tasks < P.ntasks || cap_edges < (int)P.nedges) return -3;
+  for (int t = 0; t < P.ntasks; ++t) {
+    const DagTask& d = P.tasks[t];
+    const DagPlan::Info& in = P.info[t];
+    int* o = tasks_out + (size_t)t * 24;
+    o[0] = d.kind == DAG_KIND_LEAF ? 1 : 0;
+    o[1] = in.bt;
+    o[2] = (d.kind >> 2) & 1;
+    o[3] = (d.kind >> 1) & 1;
+    o[4] = in.beta;
+    const DagPlan::Region* rg[3] = {&in.c, &in.a, &in.b};
+    for (int q = 0; q < 3; ++q) {
+      o[5 + 5 * q] = rg[q]->buf;
+      o[6 + 5 * q] = rg[q]->r0;
+      o[7 + 5 * q] = rg[q]->r1;
+      o[8 + 5 * q] = rg[q]->c0;
+      o[9 + 5 * q] = rg[q]->c1;
+    }
+    o[20] = d.npred;
+    o[21] = d.succ_begin;
+    o[22] = d.succ_count;
+    o[23] = d.ring;
+    alpha_out[t] = in.alpha;
+  }
+  memcpy(succ_out, P.succ.data(), P.succ.size() * sizeof(int));
+  return 0;
 }
 
 }  // extern "C"

@@ -23,8 +23,23 @@
 
 namespace gpc {
 
+// Recording mode (dag.h): instead of launching, the plan appends every product and every leaf to a list, in launch
+// order -- the tile-level dataflow schedule is derived from exactly the launches the stream-ordered schedule would
+// have issued, so both run the same tile arithmetic.
+struct PlanRecorder {
+  struct Op {
+    int kind;  // 0: product (g, akm, bkm), 1: leaf at diagonal offset `off`
+    GemmArgs g;
+    bool akm, bkm;
+    int off;
+  };
+  std::vector<Op> ops;
+  bool unsupported = false;  // the plan asked for something the dataflow kernel does not do (L21 copies, stable leaves)
+};
+
 template <typename T>
 struct Factor {
+  PlanRecorder* rec = nullptr;
   hipStream_t st;
   int batch;
   int npad;
@@ -123,6 +138,10 @@ struct Factor {
     g.tiles_n = N / TILE;
     flops += gemm_flops(g, batch);
     ++launches;
+    if (rec) {
+      rec->ops.push_back({0, g, akm, bkm, 0});
+      return;
+    }
     int* slot = nullptr;  // CTR_STRIDE counters per persistent launch
     // only launches that will run in the persistent form take a slot: a factorization of npad = 8192 or
     // 16384 has 250-500 launches, and the big ones (which need the slots) come last in the order
@@ -145,6 +164,13 @@ struct Factor {
   void potrf_inv(int off, int n, bool need_inv, bool keep_L) {
     keep_L = keep_L || stable;
     if (n == TILE) {
+      if (rec) {
+        if (stable) rec->unsupported = true;
+        rec->ops.push_back({1, GemmArgs{}, false, false, off});
+        flops += (2.0 / 3.0) * TILE * (double)TILE * TILE * batch;
+        ++launches;
+        return;
+      }
       need_rows(off + TILE);
       launch_leaf<T>(st, batch, blk(A, off, off), sA, npad, blk(W, off, off), sW, npad, off, logdet, info,
                      std::max(0, std::min(TILE, nvalid - off)), stable);
@@ -174,7 +200,7 @@ struct Factor {
     {
       GemmArgs gs = make_args(blk(A, o2, o2), sA, blk(Tm, o2, o1), sT, blk(Tm, o2, o1), sT, n2, n2, n1, -1.0, 1,
                               KLO_ZERO, KHI_FULL, 1);
-      if (need_inv && !defer && dual_launch && gemm_is_small(gs, batch)) {
+      if (need_inv && !defer && dual_launch && !rec && gemm_is_small(gs, batch)) {
         GemmArgs gu = make_args(blk(A, o2, o1), sA, blk(Tm, o2, o1), sT, blk(W, o1, o1), sW, n2, n1, n1, 1.0, 0,
                                 KLO_COL, KHI_FULL, 0);
         if (gemm_is_small(gu, batch)) {
@@ -217,7 +243,8 @@ struct Factor {
     }
     // L21 back into A: only where L must survive as the Cholesky factor (posteriors).  The blocked forward solve
     // of an NLL-only evaluation reads L21 where it was computed, in the scratch (forward_solve below).
-    if (keep_L) {
+    if (keep_L && rec) rec->unsupported = true;
+    if (keep_L && !rec) {
       dim3 grid((n1 + 64 * MM<T>::VEC - 1) / (64 * MM<T>::VEC), n2 / 32, batch), block(64, 4);
       hipLaunchKernelGGL((rect_copy_kernel<T>), grid, block, 0, st, (const T*)blk(Tm, o2, o1), sT, npad,
                          blk(A, o2, o1), sA, npad, n2, n1);

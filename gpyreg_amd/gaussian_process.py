@@ -960,8 +960,10 @@ class GP:
             p._have = {"alpha": False, "sW": False, "L": False}
 
     @_on_device
-    def _compute_posteriors(self, hyp):
-        """S x ``__core_computation(hyp, 0, 0)`` (reference :876-879) in one batch.  Under a process
+    def _compute_posteriors(self, hyp, shard=None):
+        """S x ``__core_computation(hyp, 0, 0)`` (reference :876-879) in one batch.  ``shard``: the caller's decision
+        (``None``: this GP's ``shard`` attribute) -- an argument, so that a rank-local rebuild never flips an attribute
+        other threads of the process read on their way into a collective.  Under a process
         group the samples are block-partitioned: this rank factors and keeps ONLY its block
         (``_post_range``); ``sn2_mult`` / ``L_chol`` of every sample are exchanged, the factors never are.
         ``Posterior.alpha/.sW/.L`` of a sample that lives on another rank read as ``None``."""
@@ -983,7 +985,7 @@ class GP:
             made["handle"], made["lo"], made["hi"] = handle, lo, hi
             return np.stack([mult, lchol.astype(float)], axis=1), info != 0
 
-        sharded = self.shard and S > 1 and _sh.active_group(self.process_group) is not None
+        sharded = (self.shard if shard is None else shard) and S > 1 and _sh.active_group(self.process_group) is not None
         try:
             if sharded:
                 full, bad = _sh.gather_rows(S, 2, local, self.process_group, _sh.fingerprint(hyp))
@@ -1109,13 +1111,9 @@ class GP:
         self._rebuild = False
         old = self.posteriors
         self.posteriors = np.empty(old.size, dtype=object)
-        shard = self.shard
-        if not self.__dict__.get("_rebuild_sharded", False):
-            self.shard = False
-        try:
-            self._compute_posteriors(np.stack([p.hyp for p in old]))
-        finally:
-            self.shard = shard
+        # (rank-local unless the set was sharded; passed down, never toggled on the object: ADVICE r4)
+        self._compute_posteriors(np.stack([p.hyp for p in old]),
+                                 shard=self.shard and self.__dict__.get("_rebuild_sharded", False))
         for i, p in enumerate(old):
             q = self.posteriors[i]
             p._handle, p._index, p._owner = q._handle, q._index, None

@@ -48,12 +48,12 @@ def _dist():
 # to complete one with freshly allocated tensors, a pageable upload and `.cpu()`).  Per (rows, columns, world, device):
 # the device block and result, and pinned host images of both (asynchronous copies either way).  A set is taken for the
 # life of one _Gather and handed back when it ends -- by `result`, also when the wait raises -- so two gathers in flight
-# never share one.  ONLY small, fixed shapes are pooled: the frame of `gather_rows` and blocks up to
-# _POOL_MAX_BYTES; the gathers of predict / predict_full / quad, whose width is the number of query points, take fresh
-# buffers and drop them, and the pool as a whole is capped at _POOL_BUDGET bytes (least recently used sets go first).
+# never share one.  The pool is BOUNDED: blocks beyond _POOL_MAX_BYTES per rank are never kept, and the free
+# sets together hold at most _POOL_BUDGET bytes -- the least recently used shapes go first -- so a loop over varying
+# numbers of query points (predict / predict_full / quad gather M columns) cannot grow pinned memory without bound.
 _POOL = {}  # key -> list of free buffer sets; dict order = recency of use
-_POOL_MAX_BYTES = 64 << 10   # per-rank block size up to which a shape is pooled
-_POOL_BUDGET = 8 << 20       # bytes of device (and as many pinned host) memory the free sets may hold
+_POOL_MAX_BYTES = 4 << 20    # per-rank block size up to which a shape is pooled (a pinned allocation costs ~60 us)
+_POOL_BUDGET = 64 << 20      # bytes of device (and as many pinned host) memory the free sets may hold
 _pool_bytes = [0]
 
 
@@ -76,7 +76,11 @@ def _buffers(maxrows, C, world, dev):
     out = torch.empty((world * maxrows, C), dtype=torch.float64, device=dev)
     hin = torch.zeros((maxrows, C), dtype=torch.float64, pin_memory=cuda) if cuda else None
     hout = torch.empty((world * maxrows, C), dtype=torch.float64, pin_memory=cuda) if cuda else None
-    return key, (buf, out, hin, hout)
+    # NumPy views of the host images (and of the CPU tensors of a gloo group): filling and reading them costs a
+    # memcpy, not a torch indexing call each
+    vin = (hin if cuda else buf).numpy()
+    vout = (hout if cuda else out).numpy()
+    return key, (buf, out, hin, hout, vin, vout)
 
 
 def _give_back(key, bufs):
@@ -114,20 +118,15 @@ class _Gather:
         self.maxrows = -(-S // self.world)
         backend = dist.get_backend(group)
         dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-        self.key, (buf, out, hin, hout) = _buffers(self.maxrows, C, self.world, dev)
-        self.bufs = (buf, out, hin, hout)  # held until the collective has completed
+        self.key, self.bufs = _buffers(self.maxrows, C, self.world, dev)  # held until the collective has completed
+        buf, out, hin, hout, vin, vout = self.bufs
         try:
             n = local.shape[0]
-            src = torch.from_numpy(np.ascontiguousarray(local, dtype=np.float64))
+            vin[:n] = local
+            if n < self.maxrows:
+                vin[n:] = 0.0
             if hin is not None:  # device group: through the pinned image, asynchronously on the current stream
-                if n < self.maxrows:
-                    hin[n:].zero_()
-                hin[:n] = src
                 buf.copy_(hin, non_blocking=True)
-            else:
-                if n < self.maxrows:
-                    buf[n:].zero_()
-                buf[:n] = src
             self.work = dist.all_gather_into_tensor(out, buf, group=group, async_op=True)
         except BaseException:
             self.bufs = None  # (not handed back: their state is unknown)
@@ -136,15 +135,13 @@ class _Gather:
     def result(self) -> np.ndarray:
         import torch
 
-        buf, out, hin, hout = self.bufs
+        buf, out, hin, hout, vin, vout = self.bufs
         try:
             self.work.wait()
             if hout is not None:
                 hout.copy_(out, non_blocking=True)
                 torch.cuda.current_stream().synchronize()
-                full = hout.numpy().reshape(self.world, self.maxrows, -1)
-            else:
-                full = out.numpy().reshape(self.world, self.maxrows, -1)
+            full = vout.reshape(self.world, self.maxrows, -1)
             if self.raw:
                 return full.copy()
             rows = []

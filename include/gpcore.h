@@ -228,6 +228,19 @@ int gpc_debug_leaf(gpc_ctx* ctx, int dtype, const double* A, double* L, double* 
 int gpc_debug_factor(gpc_ctx* ctx, int dtype, int n, const double* A, double* L,
                      double* W, double* Ainv, double* logdet, int* info);
 
+/* Debug: wrapping-sum hash of every 128 x 128 tile of one workspace matrix as the LAST call left it (which: 0 = A, 1 = W,
+ * 2 = T; sample: position in the last chunk); out[(npad/128)^2].  Finds the tile where two schedules differ.          */
+int gpc_debug_workspace_hash(gpc_ctx* ctx, int dtype, int which, int sample, unsigned long long* out);
+/* The tile-task graph of the dataflow schedule (gpyreg_amd/csrc/dag.h) for an npad x npad factorization --
+ * HOST ONLY, no device needed: tests/test_dag_model.py executes it with NumPy tiles in random valid orders.
+ * plan: 0 = NLL only (blocked solves above nll_blk rows when nll_blk > 0), 1 = factor + inverse + W^T W,
+ * 2 = factor + inverse.  counts[4] = tasks, edges, launches, leaves.  With tasks_out == NULL only the counts are
+ * written.  tasks_out: 24 ints per task [is_leaf, tile, a_kmajor, b_kmajor, beta, C/A/B region as (buffer, r0, r1,
+ * c0, c1) each, predecessors, first successor, successors, ring]; alpha_out: one double per task; succ_out: the
+ * successor lists.  Returns 0, -1 (plan not supported), -2 (bad arguments), -3 (buffers too small).               */
+int gpc_debug_dag(int npad, int plan, int nll_blk, int small_tiles, int* counts, int* tasks_out,
+                  double* alpha_out, int* succ_out, int cap_tasks, int cap_edges);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,103 @@
+"""The tile-level dataflow schedule (gpyreg_amd/csrc/dag.h; option "dag") against the stream-ordered schedule of
+plan.h: the same tile arithmetic executed by dependency counters instead of kernel boundaries, so every result must be
+IDENTICAL BIT FOR BIT -- NLL only, NLL + gradient, fp64 and fp32, one sample and batches, sizes with a padded last leaf,
+uneven splits of the recursion, 64-tile / 128-tile / mixed cuts, W^T W inside and outside the graph.  And the safety
+net: a graph that cannot make progress (test hook: no leaf server is started) aborts after its bounded wait and the call
+is answered by the stream-ordered schedule -- same bits, no hang, no error.
+Reference arithmetic being scheduled: gaussian_process.py:2415-2417 (Cholesky), :2477-2484 (the inverse)."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from gpyreg_amd import _lib
+
+    return _lib.context(0)
+
+
+def _eval(N, S, dtype, grad):
+    import bench
+
+    X, y, hyp = bench.synthetic_problem(3, S)
+    gp = bench.make_gp(3, dtype)
+    gp.update(X_new=X, y_new=y, hyp=hyp[:1], compute_posterior=False)
+    return gp.nll_batch(hyp, compute_grad=grad)
+
+
+def _both(ctx, N, S, dtype, grad, **opts):
+    import bench
+
+    cfg = dict(bench.CONFIGS[3])
+    prev = {k: ctx.get_option(k) for k in opts}
+    try:
+        bench.CONFIGS[3] = dict(cfg, N=N)
+        ctx.set_option("dag", 0)
+        ref = _eval(N, S, dtype, grad)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        ctx.set_option("dag", 1)
+        runs0, aborts0 = ctx.get_option("dag_runs"), ctx.get_option("dag_aborts")
+        got = _eval(N, S, dtype, grad)
+        return ref, got, ctx.get_option("dag_runs") - runs0, ctx.get_option("dag_aborts") - aborts0
+    finally:
+        bench.CONFIGS[3] = cfg
+        ctx.set_option("dag", 0)
+        for k, v in prev.items():
+            ctx.set_option(k, v)
+
+
+@pytest.mark.parametrize("N,S,dtype,grad,opts", [
+    (300, 1, "f64", True, {}),                           # 3 leaves, uneven split, padded last leaf
+    (700, 5, "f64", True, {}),                           # 6 leaves; every launch as 64-tiles
+    (700, 5, "f64", False, {}),                          # NLL only, left children inverted
+    (1000, 3, "f64", True, {"dag_small_tiles": 0}),      # every launch as 128-tiles
+    (1500, 9, "f64", True, {"dag_small_tiles": 6}),      # mixed cuts, more samples than bulk rings
+    (2304, 4, "f64", True, {"dag_lauum": 0}),            # W^T W as its own launch behind the graph
+    (2304, 4, "f64", False, {}),                         # NLL only with blocked solves above 512 rows
+    (2100, 2, "f32", True, {}),                          # fp32 (two-level accumulation in the tiles)
+    (2100, 2, "f32", False, {}),
+    (4096, 2, "f64", True, {}),                          # BASELINE cfg3's per-GPU batch at 8 GPUs
+])
+def test_graph_equals_stream_order_bit_for_bit(ctx, N, S, dtype, grad, opts):
+    ref, got, runs, aborts = _both(ctx, N, S, dtype, grad, **opts)
+    assert runs >= 1 and aborts == 0, (runs, aborts)
+    assert np.array_equal(ref[0], got[0]), (ref[0], got[0])
+    if grad:
+        assert np.array_equal(ref[1], got[1], equal_nan=True)
+
+
+def test_a_stalled_graph_aborts_and_the_stream_ordered_schedule_answers(ctx):
+    """No leaf server is started (test hook): the first leaf never runs, every workgroup's bounded wait runs out, the
+    abort word comes back with the results, and the call is answered by the stream-ordered schedule."""
+    ref, got, runs, aborts = _both(ctx, 700, 3, "f64", True, dag_leaf_blocks=-1, dag_timeout_ms=30)
+    assert runs == 1 and aborts == 1
+    assert np.array_equal(ref[0], got[0]) and np.array_equal(ref[1], got[1])
+
+
+def test_non_positive_definite_sample_inside_a_graph(ctx):
+    """A sample whose factorization fails in a leaf (duplicate points, huge signal variance) leaves the graph with its
+    `info` set like any stream-ordered leaf would: the jitter escalation follows and ends on the same level and bits."""
+    import bench
+
+    cfg = dict(bench.CONFIGS[3])
+    try:
+        bench.CONFIGS[3] = dict(cfg, N=600)
+        X, y, hyp = bench.synthetic_problem(3, 3)
+        X[300:] = X[:300]        # duplicate points ...
+        hyp[:, 10] = 12.0        # ... under a huge signal variance (the "jitter_high" recipe of the core fixtures)
+        hyp[:, 11] = np.log(1.1e-3)
+        res = []
+        for dag in (0, 1):
+            ctx.set_option("dag", dag)
+            gp = bench.make_gp(3, "f64")
+            gp.update(X_new=X, y_new=y, hyp=hyp)
+            res.append(gp.nll_batch(hyp, compute_grad=True) + ([p.sn2_mult for p in gp.posteriors],))
+        assert max(res[0][2]) > 1  # the case does escalate
+        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
+    finally:
+        bench.CONFIGS[3] = cfg
+        ctx.set_option("dag", 0)

@@ -176,13 +176,17 @@ def _err_worker(rank, world, port, q):
             res.append("no error")
         except sharding.ShardError as e:
             res.append("different batches" in str(e))
-        # (9) the buffer pool keeps small fixed shapes only and stays inside its budget: many distinct wide
-        # gathers leave nothing behind
+        # (9) the buffer pool is bounded: a block beyond _POOL_MAX_BYTES per rank is never kept, and many
+        # distinct shapes (a loop over varying numbers of query points) stay inside the byte budget, oldest evicted
         before = sharding.pool_bytes()
-        for M in range(9000, 9010):
+        big = sharding._POOL_MAX_BYTES // 8 + 8
+        w = np.ones((2, big))
+        sharding.gather_rows(2, big, lambda lo, hi: (w[lo:hi], np.zeros(hi - lo, bool)))
+        ok = sharding.pool_bytes() == before
+        for M in range(60000, 60000 + 80):  # ~0.5 MB per rank each, 3 x that per set: 80 sets would be ~115 MB
             w = np.ones((2, M))
             sharding.gather_rows(2, M, lambda lo, hi, w=w: (w[lo:hi], np.zeros(hi - lo, bool)))
-        res.append(sharding.pool_bytes() == before and sharding.pool_bytes() <= sharding._POOL_BUDGET)
+        res.append(ok and before < sharding.pool_bytes() <= sharding._POOL_BUDGET)
         q.put((rank, res))
     finally:
         dist.destroy_process_group()
