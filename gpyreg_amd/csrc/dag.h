@@ -39,9 +39,18 @@ namespace gpc {
 // plenty for the chain of one or two samples, share its tiles in one L2, and keep the number of workgroups that poll
 // any one ring small -- and the bulk ring of team x % nteams, and steals from the other bulk rings when both are empty.
 // (Round 5, first form: one urgent ring polled by all 496 workgroups -- 5 us per pop, 24 ms for a 1.4 ms batch.)
-enum { DAG_RING_URGENT = 0, DAG_RING_BULK0 = NQ, DAG_RING_LEAF = 2 * NQ, DAG_NRINGS = 2 * NQ + 1 };
+// Three rings per team: urgent (64-tile tasks with little slack: the chain between two leaves), crit (128-tile tasks
+// with little slack: the panel products and the first tiles of a trailing update that the next subtree waits for),
+// bulk (everything with slack: inverse products, far tiles of the updates, W^T W).  Popped in that order: FIFO rings
+// alone let a task on the critical path queue behind hundreds of tiles nobody waits for (N = 8192, one sample: 32 ms
+// against 12.8 ms stream-ordered).
+enum { DAG_RING_URGENT = 0, DAG_RING_CRIT0 = NQ, DAG_RING_BULK0 = 2 * NQ, DAG_RING_LEAF = 3 * NQ, DAG_NRINGS = 3 * NQ + 1 };
 enum { DAG_KIND_LEAF = 8 };  // 0..7: product, kind = (akm ? 4 : 0) | (bkm ? 2 : 0) | (64-tile ? 1 : 0)
 constexpr int DAG_CELL = 64;
+#ifndef GPC_DAG_HO
+#define GPC_DAG_HO 2
+#endif
+constexpr int DAG_HO = GPC_DAG_HO;  // gemm.h: 2 = plain operand loads behind the acquire, 1 = sc1 operand loads
 
 struct DagTask {  // 32 bytes, read-only on the device
   int launch;      // product: index into the launch table; leaf: diagonal offset (rows)
@@ -83,6 +92,7 @@ struct DagDev {  // kernel argument
   DagCtl* ctl;
   int ring_base[DAG_NRINGS];  // offset of each ring in `slots`
   int ntasks, S, nteams;
+  int gate, gate_task;  // samples s >= gate start when sample s - gate has finished task gate_task (0: all start at once)
   // leaf arguments
   void* A;
   void* W;
@@ -92,6 +102,7 @@ struct DagDev {  // kernel argument
   int* info;
   const unsigned short* rsv;
   long long timeout_ticks;
+  long long* trace;  // debug (GPC_DAG_TRACE): per task of sample 0 [ready, popped, started, ended, completed] wall-clock ticks, worker
 };
 
 // ---------------------------------------------------------------------------------------------------- host: the graph
@@ -102,6 +113,8 @@ struct DagPlan {
   std::vector<char> launch_akm, launch_bkm;
   std::vector<int> launch_bt;
   int ntasks = 0, nleaf = 0, n64 = 0, n128 = 0;
+  int n_urgent = 0, n_crit = 0, n_bulk = 0;  // tasks per ring class (ring capacities)
+  std::vector<int> leaf_task;               // task id of the k-th leaf
   long long nedges = 0;
   double crit_us = 0, work_us = 0;  // model figures (critical path, total work on one CU), for the log only
   // debug export (gpc_debug_dag): per task the regions it touches
@@ -147,7 +160,7 @@ inline void host_tile_of(const GemmArgs& g, int tiles_m, int tiles_n, int bx, in
 // `small_tiles`: a recorded launch with fewer 128-tiles per sample than this is cut into 64-tiles (urgent ring), the
 // others into 128-tiles (bulk rings).  bases[3] = sample 0's A, W, T; esz = sizeof(T).
 inline bool build_dag(const PlanRecorder& rec, const void* const bases[3], int npad, size_t esz, int small_tiles,
-                      DagPlan& P, bool want_info = false) {
+                      DagPlan& P, bool want_info = false, double crit_frac = 0.15) {
   if (rec.unsupported) return false;
   const int nc = npad / DAG_CELL;
   const size_t ncell = (size_t)3 * nc * nc;
@@ -318,6 +331,24 @@ inline bool build_dag(const PlanRecorder& rec, const void* const bases[3], int n
     int* b = P.succ.data() + P.tasks[t].succ_begin;
     std::stable_sort(b, b + P.tasks[t].succ_count, [&](int x, int y) { return blevel[x] > blevel[y]; });
   }
+  // slack of a task = critical path - (longest path to its start + longest path from its start to the end)
+  std::vector<double> tlevel(P.ntasks, 0.0);
+  for (int t = 0; t < P.ntasks; ++t)
+    for (int i = 0; i < P.tasks[t].succ_count; ++i) {
+      const int t2 = P.succ[P.tasks[t].succ_begin + i];
+      tlevel[t2] = std::max(tlevel[t2], tlevel[t] + dur[t]);
+    }
+  for (int t = 0; t < P.ntasks; ++t) {
+    DagTask& d = P.tasks[t];
+    if (d.kind == DAG_KIND_LEAF) {
+      P.leaf_task.push_back(t);
+      continue;
+    }
+    const double slack = P.crit_us - (tlevel[t] + blevel[t]);
+    const bool critical = slack < crit_frac * P.crit_us;
+    d.ring = critical ? ((d.kind & 1) ? DAG_RING_URGENT : DAG_RING_CRIT0) : DAG_RING_BULK0;
+    (d.ring == DAG_RING_URGENT ? P.n_urgent : (d.ring == DAG_RING_CRIT0 ? P.n_crit : P.n_bulk))++;
+  }
   return true;
 }
 
@@ -326,6 +357,7 @@ __device__ __forceinline__ int dag_ld(const int* p) { return __hip_atomic_load(p
 
 // Push task (s, t): entry = s * ntasks + t + 1 (0 = slot not yet written).
 __device__ __forceinline__ void dag_push(const DagDev& d, int s, int t) {
+  if (d.trace && s == 0) d.trace[(size_t)t * 6 + 0] = wall_clock64();
   int ring = d.tasks[t].ring;
   if (ring != DAG_RING_LEAF) ring += s % d.nteams;
   const int pos = __hip_atomic_fetch_add(d.ctl->ring[ring].tail(), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -356,12 +388,21 @@ __device__ __forceinline__ int dag_complete(const DagDev& d, int s, int t, bool 
       if (m) {
         const int src = __builtin_ctzll(m);
         kept = __shfl(t2, src, 64);
-        if (lane == src) ready = 0;  // (not pushed)
+        if (lane == src) {
+          ready = 0;  // (not pushed)
+          if (d.trace && s == 0) d.trace[(size_t)t2 * 6 + 0] = -wall_clock64();  // negative: kept, not pushed
+        }
       }
     }
     if (ready) dag_push(d, s, t2);
   }
-  if (lane == 0) __hip_atomic_fetch_sub(&d.ctl->remaining, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (lane == 0) {
+    if (d.gate > 0 && t == d.gate_task && s + d.gate < d.S) {  // the sample `gate` behind this one may start
+      const int old = __hip_atomic_fetch_sub(d.pending + (size_t)(s + d.gate) * d.ntasks, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old == 1) dag_push(d, s + d.gate, 0);
+    }
+    __hip_atomic_fetch_sub(&d.ctl->remaining, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   return kept < 0 ? -1 : s * d.ntasks + kept;
 }
 
@@ -373,13 +414,15 @@ __device__ __forceinline__ int dag_complete(const DagDev& d, int s, int t, bool 
 __device__ __forceinline__ int dag_pop(const DagDev& d, int urgent, int home, bool steal) {
   const int lane = threadIdx.x & 63;
   const long long t0 = wall_clock64();
+  const int crit = steal ? home - DAG_RING_BULK0 + DAG_RING_CRIT0 : -1;  // (GEMM workers; a leaf server has its one ring)
   int idle = 0;
   for (;;) {
     const bool wide = steal && (idle & 7) == 7;
     // lane r < DAG_NRINGS: (head, tail) of ring r -- only the lanes of the rings looked at in this round load;
-    // lane DAG_NRINGS: abort and remaining (one 8-byte... two words of the status line)
+    // lanes DAG_NRINGS, DAG_NRINGS + 1: the two status words
     int h = 0, tl = 0;
-    const bool look = lane == urgent || lane == home || (wide && lane >= DAG_RING_BULK0 && lane < DAG_RING_BULK0 + d.nteams);
+    const bool look = lane == urgent || lane == crit || lane == home ||
+                      (wide && lane >= DAG_RING_CRIT0 && lane < DAG_RING_LEAF && (lane - DAG_RING_CRIT0) % NQ < d.nteams);
     if (look) {
       const unsigned long long v = __hip_atomic_load(&d.ctl->ring[lane].ht, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       h = (int)(unsigned)v;
@@ -396,12 +439,18 @@ __device__ __forceinline__ int dag_pop(const DagDev& d, int urgent, int home, bo
       int ring;
       if (urgent >= 0 && ((ne >> urgent) & 1ull))
         ring = urgent;
+      else if (crit >= 0 && ((ne >> crit) & 1ull))
+        ring = crit;
       else if ((ne >> home) & 1ull)
         ring = home;
       else {
-        // another team's bulk ring: start the search behind the own one, so that thieves spread out
-        const unsigned long long rot = (ne >> home) | (ne << (64 - home));
-        ring = (home + __builtin_ctzll(rot)) % 64;
+        // another team's rings: its crit ring before any bulk ring; the search starts behind the own team, so that
+        // thieves spread out
+        const unsigned long long cm = (ne >> DAG_RING_CRIT0) & ((1ull << NQ) - 1), bm = (ne >> DAG_RING_BULK0) & ((1ull << NQ) - 1);
+        const int me = home - DAG_RING_BULK0;
+        const unsigned long long pick = cm ? cm : bm;
+        const unsigned long long rot = ((pick >> me) | (pick << (NQ - me))) & ((1ull << NQ) - 1);
+        ring = (cm ? DAG_RING_CRIT0 : DAG_RING_BULK0) + (me + __builtin_ctzll(rot)) % NQ;
       }
       const int hh = __shfl(h, ring, 64);
       int got = 0;
@@ -432,16 +481,25 @@ __device__ __forceinline__ int dag_pop(const DagDev& d, int urgent, int home, bo
       }
       continue;  // lost the race for that head: look again
     }
-    // nothing: back off (64 cycles per unit; 2 -> 32 units, about 0.05 -> 0.9 us), fast again after every task
+    // nothing: back off.  Every poll is a coherent load that goes to the memory fabric, and the rings' lines live in ONE
+    // channel: 430 idle workgroups polling every microsecond slowed EVERY memory access of the working ones (a 64-tile
+    // task of k = 128 ran 15-40 us instead of 5, a leaf 40 instead of 22).  Fast for a few rounds after a task (the
+    // next one of a chain comes within microseconds), then about 1 us for the workgroups that serve an urgent or the
+    // leaf ring and about 14 us for the others (bulk tasks run for hundreds of microseconds).
     ++idle;
-    const int nap = idle < 4 ? 2 : (idle < 16 ? 8 : 32);
-    if (nap == 2)
+    if (idle < 4) {
       __builtin_amdgcn_s_sleep(2);
-    else if (nap == 8)
-      __builtin_amdgcn_s_sleep(8);
-    else
-      __builtin_amdgcn_s_sleep(32);
-    if ((idle & 255) == 0 && wall_clock64() - t0 > d.timeout_ticks) {
+    } else if (idle < 24) {
+      __builtin_amdgcn_s_sleep(16);
+    } else if (urgent >= 0 || !steal) {
+      __builtin_amdgcn_s_sleep(40);
+    } else {
+      __builtin_amdgcn_s_sleep(127);
+      __builtin_amdgcn_s_sleep(127);
+      __builtin_amdgcn_s_sleep(127);
+      __builtin_amdgcn_s_sleep(127);
+    }
+    if ((idle & 63) == 0 && wall_clock64() - t0 > d.timeout_ticks) {
       if (lane == 0) __hip_atomic_store(&d.ctl->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return -1;
     }
@@ -469,6 +527,7 @@ __global__ __launch_bounds__(256, 2) void dag_worker_kernel(DagDev d) {
       const int e = kept >= 0 ? kept : dag_pop(d, urgent, home, true);
       c_pop += wall_clock64() - c0;
       c0 = wall_clock64();
+      if (d.trace && threadIdx.x == 0 && e >= 0 && e / d.ntasks == 0) d.trace[(size_t)(e % d.ntasks) * 6 + 2] = c0;
       // ONE agent-scope acquire for everything the predecessors stored (invalidates this CU's L1), waited for before
       // the barrier that releases the other waves
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -495,25 +554,32 @@ __global__ __launch_bounds__(256, 2) void dag_worker_kernel(DagDev d) {
     }
     c0 = wall_clock64();
     ++n_task;
+    if (d.trace && threadIdx.x == 0 && e / d.ntasks == 0) {
+      long long* tr = d.trace + (size_t)(e % d.ntasks) * 6;
+      tr[1] = c0 - 0;  // popped + acquired + both barriers passed
+      tr[5] = (long long)blockIdx.x | ((long long)x << 32);
+    }
     const int s = e / d.ntasks, t = e - s * d.ntasks;
     const DagTask tk = d.tasks[t];
     const GemmArgs g = d.launches[__builtin_amdgcn_readfirstlane(tk.launch)];
     const int bx = __builtin_amdgcn_readfirstlane(tk.bx);
     switch (__builtin_amdgcn_readfirstlane(tk.kind)) {
-      case 0: gemm_tile<T, false, false, 128, 4, 1>(g, bx, s, smem); break;
-      case 1: gemm_tile<T, false, false, 64, 4, 1>(g, bx, s, smem); break;
-      case 2: gemm_tile<T, false, true, 128, 4, 1>(g, bx, s, smem); break;
-      case 3: gemm_tile<T, false, true, 64, 4, 1>(g, bx, s, smem); break;
-      case 6: gemm_tile<T, true, true, 128, 4, 1>(g, bx, s, smem); break;
-      case 7: gemm_tile<T, true, true, 64, 4, 1>(g, bx, s, smem); break;
+      case 0: gemm_tile<T, false, false, 128, 4, DAG_HO>(g, bx, s, smem); break;
+      case 1: gemm_tile<T, false, false, 64, 4, DAG_HO>(g, bx, s, smem); break;
+      case 2: gemm_tile<T, false, true, 128, 4, DAG_HO>(g, bx, s, smem); break;
+      case 3: gemm_tile<T, false, true, 64, 4, DAG_HO>(g, bx, s, smem); break;
+      case 6: gemm_tile<T, true, true, 128, 4, DAG_HO>(g, bx, s, smem); break;
+      case 7: gemm_tile<T, true, true, 64, 4, DAG_HO>(g, bx, s, smem); break;
       default: break;  // (no other kind is ever routed to a worker ring)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its write-through stores have left
     __syncthreads();
     c_exec += wall_clock64() - c0;
     c0 = wall_clock64();
+    if (d.trace && threadIdx.x == 0 && s == 0) d.trace[(size_t)t * 6 + 3] = c0;
     if (threadIdx.x < 64) kept = dag_complete(d, s, t, true);
     c_done += wall_clock64() - c0;
+    if (d.trace && threadIdx.x == 0 && s == 0) d.trace[(size_t)t * 6 + 4] = wall_clock64();
   }
 }
 
@@ -546,6 +612,11 @@ __global__ __launch_bounds__(256, 1) void dag_leaf_kernel(DagDev d, int fault) {
       return;
     }
     const int s = e / d.ntasks, t = e - s * d.ntasks;
+    if (d.trace && threadIdx.x == 0 && s == 0) {
+      d.trace[(size_t)t * 6 + 1] = wall_clock64();
+      d.trace[(size_t)t * 6 + 2] = d.trace[(size_t)t * 6 + 1];
+      d.trace[(size_t)t * 6 + 5] = -1 - (long long)blockIdx.x;
+    }
     const int off = __builtin_amdgcn_readfirstlane(d.tasks[t].launch);
     T* Ab = reinterpret_cast<T*>(d.A) + (size_t)s * d.sA + (size_t)off * d.npad + off;
     T* Wb = reinterpret_cast<T*>(d.W) + (size_t)s * d.sW + (size_t)off * d.npad + off;
@@ -553,10 +624,12 @@ __global__ __launch_bounds__(256, 1) void dag_leaf_kernel(DagDev d, int fault) {
     // plain stores: every storing wave drains, the workgroup meets, one agent-scope release writes the L2 back
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (d.trace && threadIdx.x == 0 && s == 0) d.trace[(size_t)t * 6 + 3] = wall_clock64();
     if (threadIdx.x < 64) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       (void)dag_complete(d, s, t, false);
+      if (d.trace && threadIdx.x == 0 && s == 0) d.trace[(size_t)t * 6 + 4] = wall_clock64();
     }
   }
 }
@@ -567,8 +640,9 @@ __global__ __launch_bounds__(256) void dag_init_kernel(DagDev d) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     const int s = (int)(i / d.ntasks), t = (int)(i - (long long)s * d.ntasks);
     const int np = d.tasks[t].npred;
-    d.pending[i] = np;
-    if (np == 0) dag_push(d, s, t);
+    const bool gated = np == 0 && d.gate > 0 && s >= d.gate;  // (the first leaf is the one task without predecessors)
+    d.pending[i] = np + (gated ? 1 : 0);
+    if (np == 0 && !gated) dag_push(d, s, t);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) d.ctl->remaining = (int)n;
   // the launch table with this run's buffer addresses

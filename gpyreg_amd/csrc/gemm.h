@@ -183,9 +183,12 @@ __device__ __forceinline__ void tri_tile(int tile, int& ti, int& tj) {
 // fill 256 CUs with 128-tiles).  Triangular k-ranges stay 128-granular in both.
 // NW = waves per block: 4 (2 x 2 waves of BT/2 x BT/2) or 8 (2 x 4 waves of BT/2 x BT/4:
 // half the accumulators per wave, so twice the waves per SIMD to cover staging and barriers).
-// HO ("hand-off", experiments only: tools/seam_probe.hip): operands are loaded with sc1 (L1-bypassing) loads and the
-// result is stored with agent-scope (write-through, sc1) stores, the forms MI355X_MICROARCH.md prescribes for bytes
-// that cross workgroups INSIDE one launch.
+// HO ("hand-off"): the result is stored with agent-scope (write-through, sc1) stores, the form MI355X_MICROARCH.md
+// prescribes for bytes that cross workgroups INSIDE one launch.  HO = 1 (tools/seam_probe.hip): operands through sc1
+// (L1-bypassing) loads as well, no fence needed.  HO = 2 (dag.h): plain operand loads -- the consumer has run ONE
+// agent-scope acquire after it learnt that its predecessors are done.  (sc1 loads of lines a write-through store has
+// just dropped from every L2 cost a trip to memory per k-slab: a 64-tile task of k = 128 took 10-40 us, a 128-tile
+// task of k = 1152 580 us.)
 template <typename T, bool AKM, bool BKM, int BT, int NW, int HO = 0, int EPI = 0>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const int by, T* __restrict__ smem) {
   using acc_t = typename MM<T>::acc_t;
@@ -264,7 +267,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
     const __amdgpu_buffer_rsrc_t rsa = make_rsrc(AKM ? A + (size_t)k0 * g.lda + m0 : A + (size_t)m0 * g.lda + k0);
     const __amdgpu_buffer_rsrc_t rsb = make_rsrc(BKM ? B + (size_t)k0 * g.ldb + n0 : B + (size_t)n0 * g.ldb + k0);
     unsigned ua = 0, ub = 0;  // slab offsets
-    constexpr int AUX = HO ? 16 : 0;
+    constexpr int AUX = HO == 1 ? 16 : 0;  // HO = 2 (dag.h): plain loads behind the consumer's agent-scope acquire
     g2r<T, AKM, BT, NT, AUX>(ra, rsa, ua, psa, toa);
     g2r<T, BKM, BT, NT, AUX>(rb, rsb, ub, psb, tob);
     r2s<T, AKM, BT, NT>(smem, ra, t);
@@ -420,7 +423,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
         for (int r = 0; r < 4; ++r) {
           const int row = m0 + wr * WTM + i * 16 + MM<T>::row_of(lane, r);
           const int col = n0 + wc * WTN + j * 16 + (lane & 15);
-          if constexpr (HO)
+          if constexpr (HO == 1)
             old[j][r] = __hip_atomic_load(&C[(size_t)row * g.ldc + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           else
             old[j][r] = C[(size_t)row * g.ldc + col];

@@ -521,6 +521,9 @@ struct gpc_ctx {
   int dag_small_tiles = 40;  // launches with fewer 128-tiles per sample than this become 64-tile tasks (urgent ring)
   int dag_lauum = 1;         // W^T W inside the graph (its tiles fill the CUs other samples' chains leave idle)
   int dag_leaf_blocks = 0;   // leaf servers; 0: min(samples, 8)
+  int dag_gate = 0;          // > 0: sample s starts when sample s - dag_gate has finished the leaf at dag_gate_pct % of its chain
+  int dag_gate_pct = 50;
+  int dag_crit_pct = 15;     // tasks with less slack than this share of the critical path go to the urgent / crit rings
   int dag_timeout_ms = 2000; // a workgroup that finds nothing to do for this long aborts the graph
   int dag_runs = 0, dag_aborts = 0;  // statistics (gpc_get_option "dag_runs" / "dag_aborts")
   bool dag_used = false;     // the pipeline in flight runs a graph: its abort word rides back with the results
@@ -1080,6 +1083,7 @@ struct Pipe {
 
   // ---- tile-level dataflow (dag.h) ----------------------------------------------------------------------------
   bool use_dag = false;  // run(): this pipeline's factorization goes through the task graph
+  int dag_trace_n = 0;
   // "dag" = -1: where the graph was measured to win
   bool dag_auto(int cnt, int npad) const { return false; }
 
@@ -1091,7 +1095,7 @@ struct Pipe {
     const unsigned long long key = (unsigned long long)npad | ((unsigned long long)sizeof(T) << 20) |
                                    ((unsigned long long)nll_blk << 24) | ((unsigned long long)full_inv << 40) |
                                    ((unsigned long long)with_lauum << 41) | ((unsigned long long)mode << 42) |
-                                   ((unsigned long long)c->dag_small_tiles << 44);
+                                   ((unsigned long long)c->dag_small_tiles << 44) | ((unsigned long long)c->dag_crit_pct << 56);
     for (auto& e : c->dag_cache)
       if (e.key == key) {
         e.last_use = ++c->dag_clock;
@@ -1132,7 +1136,7 @@ struct Pipe {
     e.last_use = ++c->dag_clock;
     const void* bases[3] = {dag_fake_base(0), dag_fake_base(1), dag_fake_base(2)};
     DagPlan& P = e.plan;
-    if (!build_dag(rec, bases, npad, sizeof(T), c->dag_small_tiles, P)) {
+    if (!build_dag(rec, bases, npad, sizeof(T), c->dag_small_tiles, P, false, c->dag_crit_pct / 100.0)) {
       P = DagPlan{};
       P.work_us = F.flops;
       *flops1 = F.flops;
@@ -1140,8 +1144,8 @@ struct Pipe {
     }
     if (getenv("GPC_DAG_LOG"))
       fprintf(stderr, "[gpcore] dag npad=%d nll_blk=%d lauum=%d: %d tasks (%d leaves, %d x 64, %d x 128), %lld edges, %zu launches; "
-                      "model: critical path %.0f us, work %.0f CU-us\n", npad, nll_blk, (int)with_lauum, P.ntasks, P.nleaf, P.n64, P.n128,
-              P.nedges, P.launches.size(), P.crit_us, P.work_us);
+                      "rings: %d urgent, %d crit, %d bulk; model: critical path %.0f us, work %.0f CU-us\n", npad, nll_blk, (int)with_lauum, P.ntasks, P.nleaf, P.n64, P.n128,
+              P.nedges, P.launches.size(), P.n_urgent, P.n_crit, P.n_bulk, P.crit_us, P.work_us);
     auto put = [&](DevBuf& d, const void* src, size_t n) -> hipError_t {
       hipError_t er = d.ensure(std::max<size_t>(n, 16));
       if (er != hipSuccess) return er;
@@ -1176,10 +1180,17 @@ struct Pipe {
     for (int q = 0; q < NQ; ++q) {  // team q holds the samples q, q + nteams, ...
       const int members = q < d.nteams ? (n - q + d.nteams - 1) / d.nteams : 0;
       d.ring_base[DAG_RING_URGENT + q] = off;
-      off += members * P.n64;
+      off += members * P.n_urgent;
+      d.ring_base[DAG_RING_CRIT0 + q] = off;
+      off += members * P.n_crit;
       d.ring_base[DAG_RING_BULK0 + q] = off;
-      off += members * P.n128;
+      off += members * P.n_bulk;
     }
+    // staggered starts: with more samples than teams the chains of all samples would otherwise run in phase (every
+    // sample in its latency-bound stretches at the same time, nothing to fill the chip with)
+    d.gate = c->dag_gate > 0 && c->dag_gate < n ? c->dag_gate : 0;
+    d.gate_task = P.leaf_task.empty() ? 0 : P.leaf_task[std::min<size_t>(P.leaf_task.size() - 1,
+                                                                       (size_t)(P.leaf_task.size() * (size_t)c->dag_gate_pct / 100))];
     d.ring_base[DAG_RING_LEAF] = off;
     off += n * P.nleaf;
     HIPCHK(c, c->dag_slots.ensure((size_t)std::max(off, 4) * sizeof(int)));
@@ -1210,6 +1221,13 @@ struct Pipe {
     d.info = F.info;
     d.rsv = c->rsv_tbl1.template as<unsigned short>();
     d.timeout_ticks = (long long)c->dag_timeout_ms * 100000ll;  // wall_clock64: 100 MHz
+    d.trace = nullptr;
+    if (getenv("GPC_DAG_TRACE")) {
+      HIPCHK(c, c->dbg2.ensure((size_t)P.ntasks * 6 * sizeof(long long)));
+      HIPCHK(c, hipMemsetAsync(c->dbg2.p, 0, (size_t)P.ntasks * 6 * sizeof(long long), st));
+      d.trace = c->dbg2.template as<long long>();
+      dag_trace_n = P.ntasks;
+    }
     HIPCHK(c, hipMemsetAsync(d.slots, 0, (size_t)off * sizeof(int), st));
     HIPCHK(c, hipMemsetAsync(d.ctl, 0, sizeof(DagCtl), st));
     const long long items = (long long)n * P.ntasks;
@@ -1700,6 +1718,17 @@ struct Pipe {
     HIPCHK(c, c->pin.flush_down(st));
     HIPCHK(c, hipStreamSynchronize(st));
     c->pin.finish();
+    if (c->dag_used && dag_trace_n > 0 && getenv("GPC_DAG_TRACE")) {  // sample 0's task times, one line per task, to the named file
+      std::vector<long long> tr((size_t)dag_trace_n * 6);
+      (void)hipMemcpy(tr.data(), c->dbg2.p, tr.size() * sizeof(long long), hipMemcpyDeviceToHost);
+      if (FILE* f = fopen(getenv("GPC_DAG_TRACE"), "w")) {
+        for (int t = 0; t < dag_trace_n; ++t)
+          fprintf(f, "%d %lld %lld %lld %lld %lld %lld\n", t, tr[(size_t)t * 6], tr[(size_t)t * 6 + 1], tr[(size_t)t * 6 + 2],
+                  tr[(size_t)t * 6 + 3], tr[(size_t)t * 6 + 4], tr[(size_t)t * 6 + 5]);
+        fclose(f);
+      }
+      dag_trace_n = 0;
+    }
     if (c->dag_used && getenv("GPC_DAG_STATS")) {
       DagCtl h;
       (void)hipMemcpy(&h, c->dag_ctl.p, sizeof h, hipMemcpyDeviceToHost);
@@ -3272,6 +3301,14 @@ int gpc_set_option(gpc_ctx* c, const char* name, int value) {
     c->dag_lauum = value;
   else if (n == "dag_leaf_blocks")
     c->dag_leaf_blocks = value;
+  else if (n == "dag_aborts")  // (tests: forget earlier aborts -- three of them switch the graph off for the context)
+    c->dag_aborts = value;
+  else if (n == "dag_gate")
+    c->dag_gate = value;
+  else if (n == "dag_gate_pct")
+    c->dag_gate_pct = std::max(0, std::min(100, value));
+  else if (n == "dag_crit_pct")
+    c->dag_crit_pct = std::max(0, std::min(100, value));
   else if (n == "dag_timeout_ms")
     c->dag_timeout_ms = value;
   else if (n == "check_queues")  // debug: verify the tile queues of persistent launches after every pipeline
@@ -3306,6 +3343,9 @@ int gpc_get_option(gpc_ctx* c, const char* name, int* value) {
   else if (n == "dag_small_tiles") *value = c->dag_small_tiles;
   else if (n == "dag_lauum") *value = c->dag_lauum;
   else if (n == "dag_leaf_blocks") *value = c->dag_leaf_blocks;
+  else if (n == "dag_gate") *value = c->dag_gate;
+  else if (n == "dag_gate_pct") *value = c->dag_gate_pct;
+  else if (n == "dag_crit_pct") *value = c->dag_crit_pct;
   else if (n == "dag_timeout_ms") *value = c->dag_timeout_ms;
   else if (n == "dag_runs") *value = c->dag_runs;
   else if (n == "dag_aborts") *value = c->dag_aborts;

@@ -157,6 +157,24 @@ class GP:
 
     def __init__(self, D: int, covariance: object, mean: object, noise: object,
                  device: int | None = None, dtype: str = "f64", reference_quirks: bool = False):
+        """``gpyreg.GP(D, covariance, mean, noise)`` (reference gaussian_process.py:43-62) plus ``device``, ``dtype``
+        and ``reference_quirks``.
+
+        DEFAULT DEVIATIONS FROM THE REFERENCE -- a drop-in that differs by default has to say so here.  With
+        ``reference_quirks=False`` (the default) three results are NOT the reference's numbers, because the reference's
+        own code is wrong there (each found by diffing against its printed output, each reproduced exactly with
+        ``reference_quirks=True``):
+
+        1. ``quad(compute_var=True)`` with user-provided noise ``s2``: the reference rescales by
+           ``exp(2 hyp[cov_N]) * sn2_mult`` although the factor was scaled by ``min(sn2) * sn2_mult``
+           (gaussian_process.py:1921-1922 against :1953-1958); the default here uses the factor's own scale.
+        2. ``quad`` with an isotropic squared-exponential kernel in D > 1: the reference reads the two hyperparameters
+           as ARD length scales of the first two dimensions (:1898-1903); the default uses one length scale for all.
+        3. ``update(X_new=one point, y_new, hyp=new samples)``: the reference appends under the OLD samples and drops
+           the new ones (:736-746); the default recomputes with the new ones.
+
+        Everything else -- nlZ, gradients, posteriors, predictions, lpd, fits under a fixed seed -- is held to the
+        reference's values by the golden fixtures under tests/golden/."""
         self.D = D
         self._quirks = bool(reference_quirks)
         self.covariance = covariance
