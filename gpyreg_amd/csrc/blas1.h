@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void rect_copy_kernel(const T* __restrict__ sr
 // The 4 x 4 accumulator block of the GEMM's k-step, written as one asm block so that the
 // compiler cannot put register copies between the MFMAs (a plain C++ loop over an accumulator
 // array measured 105 instead of 64 cycles per v_mfma_f64_16x16x4_f64 for that reason;
-// tools/mfma_scaling.hip).  NACC is kept as a template parameter for the C ABI's variants:
+// a round-1 probe, since removed; profiles/r01g_mfma_cadence.txt).  NACC is kept as a template parameter for the C ABI's variants:
 // every variant issues the same 16 independent MFMAs per iteration.
 #define GPC_PEAK_M(op, c, a, b) op " %" #c ", %" #a ", %" #b ", %" #c "\n"
 #define GPC_PEAK_BLOCK(op)                                                                                        \

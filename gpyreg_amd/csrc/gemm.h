@@ -189,8 +189,20 @@ __device__ __forceinline__ void tri_tile(int tile, int& ti, int& tj) {
 // agent-scope acquire after it learnt that its predecessors are done.  (sc1 loads of lines a write-through store has
 // just dropped from every L2 cost a trip to memory per k-slab: a 64-tile task of k = 128 took 10-40 us, a 128-tile
 // task of k = 1152 580 us.)
+#ifdef GPC_TILE_TRACE
+// one-off diagnosis (a library built with -DGPC_TILE_TRACE): wall-clock ticks summed per phase of gemm_tile for the
+// hand-off tiles -- [BT == 64][prologue, k-loop, epilogue stores issued, count]
+__device__ unsigned long long g_tile_trace[2][4];
+#define TILE_TS(k) do { if (HO && threadIdx.x == 0) { const long long _n = wall_clock64(); atomicAdd(&g_tile_trace[BT == 64][k], (unsigned long long)(_n - _ts)); _ts = _n; } } while (0)
+#else
+#define TILE_TS(k) do { } while (0)
+#endif
 template <typename T, bool AKM, bool BKM, int BT, int NW, int HO = 0, int EPI = 0>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const int by, T* __restrict__ smem) {
+#ifdef GPC_TILE_TRACE
+  long long _ts = wall_clock64();
+  if (HO && threadIdx.x == 0) atomicAdd(&g_tile_trace[BT == 64][3], 1ull);
+#endif
   using acc_t = typename MM<T>::acc_t;
   using vec_t = typename MM<T>::vec_t;
   constexpr int NT = 64 * NW;
@@ -278,6 +290,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
     g2r<T, AKM, BT, NT, AUX>(ra, rsa, ua, psa, toa);
     g2r<T, BKM, BT, NT, AUX>(rb, rsb, ub, psb, tob);
     __syncthreads();
+    TILE_TS(0);
 
     // Software pipeline of one k-slab (KS k-steps of MRM x MRN MFMAs) out of LDS stage CUR.
     // Measured on MI355X (tools/mfma_ladder.hip, profiles/r01g_mfma_ladder.txt): the MFMA pipe
@@ -374,6 +387,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
     slab(I1{}, std::false_type{}, std::false_type{});
   }
 
+  TILE_TS(1);
   const T alpha = (T)g.alpha;
   if constexpr (EPI == 1) {
     // column sums of squares of this tile instead of the tile itself.  A lane holds 4 rows x MRN columns of each of
@@ -447,6 +461,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
           C[(size_t)row * g.ldc + col] = v;
       }
   }
+  TILE_TS(2);
 }
 
 template <typename T, bool AKM, bool BKM, int BT, int NW, int EPI = 0>

@@ -424,7 +424,7 @@ struct gpc_ctx {
   // left child inverted); -1: automatic -- 512 from npad = 2048 on, else 0.  The choice depends on the problem size
   // ONLY, never on the batch: a row of a batch must carry the bits of its single evaluation (the speculative slice
   // sampler relies on it, slice_sample.py), and the two schemes differ in rounding.
-  // Measured (tools/nll_block_sweep.py, ms per batch at block 0 / 256 / 512 / 1024): cfg3 S=16 8.85 / 8.50 / 8.41 / 8.46;
+  // Measured (round-3 sweep, script since removed; ms per batch at block 0 / 256 / 512 / 1024): cfg3 S=16 8.85 / 8.50 / 8.41 / 8.46;
   // N=8192 S=8 29.8 / 28.1 / 27.5 / 27.5; N=2048 S=16 1.98 / 1.95 / 1.89 / 2.00; single samples and small batches are
   // launch-bound and lose with the extra launches of the blocked solves (N=4096 S=1 2.28 / 2.42 / 2.30 / 2.28;
   // N=2048 S=1 0.96 / 1.01 / 0.98 / 0.98; N=1000 S=8 0.52 / 0.53 / 0.54 / 0.54): below npad = 2048 the round-2 scheme stays.
@@ -1639,7 +1639,7 @@ struct Pipe {
     // N=1000 S=8: 0.78 -> 0.54 ms (NLL), 0.92 -> 0.68 ms (gradient); N=2000 S=8 NLL 1.78 -> 1.36 ms; cfg3 NLL-only
     // 9.44 -> 9.04 ms -- and two groups by 1-2 % beyond (N=4096 S=128).
     if ((double)cnt * std::pow((double)npad / 4096.0, 3.0) <= 64.0) groups = 1;
-    // Deferred inverse products (plan.h): measured on MI355X (tools/defer_sweep.py) they pay whenever the
+    // Deferred inverse products (plan.h): measured on MI355X (round-2 sweep, script since removed) they pay whenever the
     // latency-bound phases are a visible share of the batch -- S (npad/4096)^3 <= 64 with at least 4 samples:
     // N=2048 S=16 4.42 -> 4.04 ms, N=4096 S=4 8.59 -> 7.47, N=4096 S=16 21.5 -> 20.2, N=4096 S=32 39.4 -> 38.7
     // -- and cost a little beyond (N=8192 S=64: 556 -> 584 ms).  With them one sample group is better than two.
@@ -1729,6 +1729,18 @@ struct Pipe {
       }
       dag_trace_n = 0;
     }
+#ifdef GPC_TILE_TRACE
+    if (c->dag_used && getenv("GPC_DAG_STATS")) {
+      unsigned long long tt[2][4];
+      (void)hipMemcpyFromSymbol(tt, HIP_SYMBOL(gpc::g_tile_trace), sizeof tt);
+      unsigned long long zero[2][4] = {};
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(gpc::g_tile_trace), zero, sizeof zero);
+      for (int q = 0; q < 2; ++q)
+        if (tt[q][3])
+          fprintf(stderr, "[gpcore] %s-tile tasks: %llu; us per task (thread 0): prologue %.2f, k-loop %.2f, epilogue (loads of C, stores issued) %.2f\n",
+                  q ? "64" : "128", tt[q][3], tt[q][0] / 100.0 / tt[q][3], tt[q][1] / 100.0 / tt[q][3], tt[q][2] / 100.0 / tt[q][3]);
+    }
+#endif
     if (c->dag_used && getenv("GPC_DAG_STATS")) {
       DagCtl h;
       (void)hipMemcpy(&h, c->dag_ctl.p, sizeof h, hipMemcpyDeviceToHost);
