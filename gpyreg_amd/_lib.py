@@ -378,7 +378,7 @@ class Context:
                    lower_only=False, dtype=F64, force_bt=0):
         A, B = _f64(A), _f64(B)
         Cm = _f64(Cm).copy()
-        flags = int(bool(lower_only)) | {0: 0, 64: 0x100, 128: 0x200}[force_bt]
+        flags = int(bool(lower_only)) | {0: 0, 64: 0x100, 128: 0x200, 12864: 0x400}[force_bt]
         rc = self._lib.gpc_debug_gemm(self._h, dtype, M, N, K, int(a_kmajor), int(b_kmajor),
                                       float(alpha), int(beta), klo, khi, flags, _ptr(A),
                                       _ptr(B), _ptr(Cm))

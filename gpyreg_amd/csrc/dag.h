@@ -92,6 +92,7 @@ struct DagDev {  // kernel argument
   DagCtl* ctl;
   int ring_base[DAG_NRINGS];  // offset of each ring in `slots`
   int ntasks, S, nteams;
+  int leaf_servers;     // leaf servers launched beside the workers (0: none -- the test hook)
   int gate, gate_task;  // samples s >= gate start when sample s - gate has finished task gate_task (0: all start at once)
   // leaf arguments
   void* A;
@@ -499,9 +500,20 @@ __device__ __forceinline__ int dag_pop(const DagDev& d, int urgent, int home, bo
       __builtin_amdgcn_s_sleep(127);
       __builtin_amdgcn_s_sleep(127);
     }
-    if ((idle & 63) == 0 && wall_clock64() - t0 > d.timeout_ticks) {
-      if (lane == 0) __hip_atomic_store(&d.ctl->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return -1;
+    if ((idle & 63) == 0) {
+      const long long waited = wall_clock64() - t0;
+      if (waited > d.timeout_ticks) {
+        if (lane == 0) __hip_atomic_store(&d.ctl->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return -1;
+      }
+      // The leaf servers must be resident beside the workers.  If a millisecond into the launch not one of them has
+      // started while nothing has been computed yet, the runtime has serialised the two launches (DESIGN.md section 3
+      // step 19): give up at once -- the stream-ordered schedule answers -- instead of waiting out the long time-out.
+      if (steal && d.leaf_servers > 0 && waited > 100000 && dag_ld(&d.ctl->leaf_alive) == 0 &&
+          dag_ld(&d.ctl->remaining) == d.S * d.ntasks) {
+        if (lane == 0) __hip_atomic_store(&d.ctl->abort, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return -1;
+      }
     }
   }
 }

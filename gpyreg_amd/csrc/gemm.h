@@ -197,7 +197,11 @@ __device__ unsigned long long g_tile_trace[2][4];
 #else
 #define TILE_TS(k) do { } while (0)
 #endif
-template <typename T, bool AKM, bool BKM, int BT, int NW, int HO = 0, int EPI = 0>
+// BTN (round 5): tile COLUMNS when they differ from the tile rows BT -- the rectangular 128 x 64 tile of launches that are
+// too small for 128-tiles (one wave of tiles, as long as its longest) and run L2-bound as 64-tiles: half the tile-count
+// granularity of the one, 25 % fewer operand bytes per flop than the other.  Triangular k-ranges stay 128-granular, every
+// element keeps its k-order: the bits do not depend on the tile shape.
+template <typename T, bool AKM, bool BKM, int BT, int NW, int HO = 0, int EPI = 0, int BTN = BT>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const int by, T* __restrict__ smem) {
 #ifdef GPC_TILE_TRACE
   long long _ts = wall_clock64();
@@ -206,12 +210,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
   using acc_t = typename MM<T>::acc_t;
   using vec_t = typename MM<T>::vec_t;
   constexpr int NT = 64 * NW;
-  constexpr int NV = (BT * BKT_v<T>) / (NT * MM<T>::VEC);
-  constexpr int OPSZ = opsz_of<T>(BT);
+  constexpr int NVA = (BT * BKT_v<T>) / (NT * MM<T>::VEC), NVB = (BTN * BKT_v<T>) / (NT * MM<T>::VEC);
+  constexpr int OPSZA = opsz_of<T>(BT), OPSZB = opsz_of<T>(BTN), STG = OPSZA + OPSZB;  // one LDS stage: [A | B]
   constexpr int WCOLS = NW / 2;        // waves along n
   constexpr int WTM = BT / 2;          // wave tile rows
-  constexpr int WTN = BT / WCOLS;      // wave tile cols
+  constexpr int WTN = BTN / WCOLS;     // wave tile cols
   constexpr int MRM = WTM / 16, MRN = WTN / 16;
+  static_assert(NVA >= 1 && NVB >= 1 && MRM >= 1 && MRN >= 1, "tile shape");
   const int t = threadIdx.x;
   const int lane = t & 63, w = t >> 6, wr = w / WCOLS, wc = w % WCOLS;
 
@@ -221,7 +226,17 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
   // blocks on one operand panel.
   int ti, tj;
   if (g.lower_only) {
-    tri_tile(bx, ti, tj);  // ti ascending: longest first for KLO_ROW (lauum), uniform for syrk
+    if constexpr (BTN == BT) {
+      tri_tile(bx, ti, tj);  // ti ascending: longest first for KLO_ROW (lauum), uniform for syrk
+    } else {
+      static_assert(BT == 2 * BTN, "lower tiles of a rectangular launch: two tile columns per tile row");
+      // tile row ti holds the columns 0 .. 2 ti + 1: ti (ti + 1) tiles come before it
+      int i = (int)((sqrtf(4.f * (float)bx + 1.f) - 1.f) * 0.5f);
+      while (i * (i + 1) > bx) --i;
+      while ((i + 1) * (i + 2) <= bx) ++i;
+      ti = i;
+      tj = bx - i * (i + 1);
+    }
   } else if (g.khi == KHI_COL) {
     tj = g.tiles_n - 1 - bx / g.tiles_m;
     ti = bx % g.tiles_m;
@@ -235,7 +250,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
     ti = bx / g.tiles_n;
     tj = bx % g.tiles_n;
   }
-  const int m0 = ti * BT, n0 = tj * BT;
+  const int m0 = ti * BT, n0 = tj * BTN;
   const int m128 = (m0 / TILE) * TILE, n128 = (n0 / TILE) * TILE;
   int k0 = g.klo == KLO_ROW ? m128 : (g.klo == KLO_COL ? n128 : 0);
   int k1 = g.khi == KHI_ROW ? m128 + TILE : (g.khi == KHI_COL ? n128 + TILE : g.K);
@@ -267,13 +282,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
   }
 
   if (nk > 0) {
-    vec_t ra[NV], rb[NV];
+    vec_t ra[NVA], rb[NVB];
     // byte offsets: per thread (fixed), per pass and per slab (block-uniform); an operand of one
     // sample is < 4 GB for every supported size (N <= 16384 fp64)
     const unsigned toa = stage_toff<T, AKM, BT, NT>(g.lda, t) * (unsigned)sizeof(T),
-                   tob = stage_toff<T, BKM, BT, NT>(g.ldb, t) * (unsigned)sizeof(T);
+                   tob = stage_toff<T, BKM, BTN, NT>(g.ldb, t) * (unsigned)sizeof(T);
     const unsigned psa = (unsigned)(stage_pstride<T, AKM, BT, NT>(g.lda) * sizeof(T)),
-                   psb = (unsigned)(stage_pstride<T, BKM, BT, NT>(g.ldb) * sizeof(T));
+                   psb = (unsigned)(stage_pstride<T, BKM, BTN, NT>(g.ldb) * sizeof(T));
     const unsigned stepa = (unsigned)((AKM ? (size_t)BKT_v<T> * g.lda : (size_t)BKT_v<T>) * sizeof(T)),
                    stepb = (unsigned)((BKM ? (size_t)BKT_v<T> * g.ldb : (size_t)BKT_v<T>) * sizeof(T));
     const __amdgpu_buffer_rsrc_t rsa = make_rsrc(AKM ? A + (size_t)k0 * g.lda + m0 : A + (size_t)m0 * g.lda + k0);
@@ -281,14 +296,14 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
     unsigned ua = 0, ub = 0;  // slab offsets
     constexpr int AUX = HO == 1 ? 16 : 0;  // HO = 2 (dag.h): plain loads behind the consumer's agent-scope acquire
     g2r<T, AKM, BT, NT, AUX>(ra, rsa, ua, psa, toa);
-    g2r<T, BKM, BT, NT, AUX>(rb, rsb, ub, psb, tob);
+    g2r<T, BKM, BTN, NT, AUX>(rb, rsb, ub, psb, tob);
     r2s<T, AKM, BT, NT>(smem, ra, t);
-    r2s<T, BKM, BT, NT>(smem + OPSZ, rb, t);
+    r2s<T, BKM, BTN, NT>(smem + OPSZA, rb, t);
     // slab 1 is in flight while slab 0 is multiplied (k-ranges are 128-granular: nk is a multiple of 128 / BKT >= 4)
     ua += stepa;
     ub += stepb;
     g2r<T, AKM, BT, NT, AUX>(ra, rsa, ua, psa, toa);
-    g2r<T, BKM, BT, NT, AUX>(rb, rsb, ub, psb, tob);
+    g2r<T, BKM, BTN, NT, AUX>(rb, rsb, ub, psb, tob);
     __syncthreads();
     TILE_TS(0);
 
@@ -308,7 +323,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
 #pragma unroll
       for (int i = 0; i < MRM; ++i) af[set][i] = frag<T, AKM, BT>(a_s, wr * WTM + i * 16, kk, lane);
 #pragma unroll
-      for (int j = 0; j < MRN; ++j) bf[set][j] = frag<T, BKM, BT>(b_s, wc * WTN + j * 16, kk, lane);
+      for (int j = 0; j < MRN; ++j) bf[set][j] = frag<T, BKM, BTN>(b_s, wc * WTN + j * 16, kk, lane);
     };
     auto mfmas = [&](int set) {
 #pragma unroll
@@ -316,17 +331,18 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
 #pragma unroll
         for (int j = 0; j < MRN; ++j) acc[i][j] = MM<T>::mma(af[set][i], bf[set][j], acc[i][j]);
     };
-    constexpr int NMEM = 2 * NV;                    // memory instructions per slab and direction
+    constexpr int NMEM = NVA + NVB;                 // memory instructions per slab and direction
     constexpr int PER = (MRM * MRN) / NMEM;         // MFMAs between two of them
-    static_assert(PER >= 1 && PER * NMEM == MRM * MRN, "interleave pattern");
+    constexpr int REM = MRM * MRN - PER * NMEM;     // (rectangular tile: 8 MFMAs, 6 memory instructions -- the last two MFMAs follow)
+    static_assert(PER >= 1, "interleave pattern");
     constexpr int KS = BKT_v<T> / 4;  // k-steps per slab: 4 (fp64) or 8 (fp32)
     static_assert(KS >= 4 && KS % 2 == 0, "fragment sets alternate per k-step and wrap per slab");
     auto slab = [&](auto cur_c, auto wr_c, auto ld_c) {
       constexpr int CUR = decltype(cur_c)::value;
       constexpr bool WR = decltype(wr_c)::value, LD = decltype(ld_c)::value;
-      const T* a_s = smem + CUR * 2 * OPSZ;
-      const T* b_s = a_s + OPSZ;
-      T* a_n = smem + (CUR ^ 1) * 2 * OPSZ;
+      const T* a_s = smem + CUR * STG;
+      const T* b_s = a_s + OPSZA;
+      T* a_n = smem + (CUR ^ 1) * STG;
 #pragma unroll
       for (int ks = 0; ks < KS - 2; ++ks) {
         load_frags((ks + 1) & 1, a_s, b_s, 4 * (ks + 1));
@@ -339,7 +355,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
       mfmas(0);
       if constexpr (WR) {
         r2s<T, AKM, BT, NT>(a_n, ra, t);
-        r2s<T, BKM, BT, NT>(a_n + OPSZ, rb, t);
+        r2s<T, BKM, BTN, NT>(a_n + OPSZA, rb, t);
       }
       __builtin_amdgcn_sched_group_barrier(0x100, MRM + MRN, 0);
 #pragma unroll
@@ -347,15 +363,16 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
         __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
         if constexpr (WR) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
       }
+      if constexpr (REM > 0) __builtin_amdgcn_sched_group_barrier(0x008, REM, 0);
       __syncthreads();
       // k-step KS-1: the global loads of the slab after next between its MFMAs
       if constexpr (LD) {
         ua += stepa;
         ub += stepb;
         g2r<T, AKM, BT, NT, AUX>(ra, rsa, ua, psa, toa);
-        g2r<T, BKM, BT, NT, AUX>(rb, rsb, ub, psb, tob);
+        g2r<T, BKM, BTN, NT, AUX>(rb, rsb, ub, psb, tob);
       }
-      if constexpr (WR) load_frags(0, a_n, a_n + OPSZ, 0);
+      if constexpr (WR) load_frags(0, a_n, a_n + OPSZA, 0);
       mfmas(1);
       if constexpr (WR) __builtin_amdgcn_sched_group_barrier(0x100, MRM + MRN, 0);
 #pragma unroll
@@ -363,10 +380,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
         __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
         if constexpr (LD) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       }
+      if constexpr (REM > 0) __builtin_amdgcn_sched_group_barrier(0x008, REM, 0);
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
-    load_frags(0, smem, smem + OPSZ, 0);
+    load_frags(0, smem, smem + OPSZA, 0);
     int it = 0;
     for (; it + 3 < nk; it += 2) {
       slab(I0{}, std::true_type{}, std::true_type{});
@@ -392,7 +410,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
   if constexpr (EPI == 1) {
     // column sums of squares of this tile instead of the tile itself.  A lane holds 4 rows x MRN columns of each of
     // its MRM fragments: rows first in the lane (fragment, then register), then the four lane groups, then the wave rows
-    static_assert(NW == 4 && BT == 128, "the reduction is laid out for 2 x 2 waves of 64 x 64");
+    static_assert(NW == 4 && BT == 128 && BTN == BT, "the reduction is laid out for 2 x 2 waves of 64 x 64");
     double cs[MRN];
 #pragma unroll
     for (int j = 0; j < MRN; ++j) {
@@ -464,9 +482,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
   TILE_TS(2);
 }
 
-template <typename T, bool AKM, bool BKM, int BT, int NW, int EPI = 0>
+template <typename T, bool AKM, bool BKM, int BT, int NW, int EPI = 0, int BTN = BT>
 __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) T smem[4 * opsz_of<T>(BT)];
+  __shared__ __attribute__((aligned(16))) T smem[2 * (opsz_of<T>(BT) + opsz_of<T>(BTN))];
   int bx = blockIdx.x, by = blockIdx.y;
   if ((g.flags & 16) && gridDim.y >= 8) {
     // (with fewer than 8 samples a contiguous range is a piece of ONE sample's longest-first tile list: the
@@ -482,7 +500,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(GemmArgs g) {
       by = wk / (int)gridDim.x;
     }
   }
-  gemm_tile<T, AKM, BKM, BT, NW, 0, EPI>(g, bx, by, smem);
+  gemm_tile<T, AKM, BKM, BT, NW, 0, EPI, BTN>(g, bx, by, smem);
 }
 
 // Two independent products in ONE launch (plan.h: the syrk A22 -= T21 T21^T and the inverse product U = T21 W11 of
@@ -613,6 +631,33 @@ inline hipError_t launch_gemm_bt(hipStream_t st, GemmArgs g, bool akm, bool bkm,
   return hipGetLastError();
 }
 
+// 128 x 64 tiles (plain launches): see gemm_tile's BTN
+template <typename T>
+inline hipError_t launch_gemm_rect(hipStream_t st, GemmArgs g, bool akm, bool bkm, int batch) {
+  constexpr int BT = 128, BTN = 64;
+  g.tiles_m = g.M / BT;
+  g.tiles_n = g.N / BTN;
+  g.flags = g_gemm_flags;
+  const int ntiles = g.lower_only ? g.tiles_m * (g.tiles_m + 1) : g.tiles_m * g.tiles_n;
+  if (ntiles <= 0 || batch <= 0) return hipSuccess;
+  g.ntiles = ntiles;
+  g.batch = batch;
+  g.ctr = nullptr;
+  g.rsv = nullptr;
+  dim3 grid(ntiles, batch), block(256);
+  if (!akm && !bkm)
+    hipLaunchKernelGGL((gemm_kernel<T, false, false, BT, 4, 0, BTN>), grid, block, 0, st, g);
+  else if (!akm && bkm)
+    hipLaunchKernelGGL((gemm_kernel<T, false, true, BT, 4, 0, BTN>), grid, block, 0, st, g);
+  else if (akm && bkm)
+    hipLaunchKernelGGL((gemm_kernel<T, true, true, BT, 4, 0, BTN>), grid, block, 0, st, g);
+  else
+    hipLaunchKernelGGL((gemm_kernel<T, true, false, BT, 4, 0, BTN>), grid, block, 0, st, g);
+  return hipGetLastError();
+}
+// launches of at least this many 128-tiles (times samples) that are still "small" take the rectangular tile; 0: never
+inline int g_rect_min_blocks = 0;  // tunable: gpc_set_option("rect_min", n) / GPC_RECT_MIN
+
 // Launches that cannot put ~2 blocks of 128-tiles on every CU use 64-tiles (4x the blocks,
 // a quarter of the work each): the deep levels of the recursion are latency-, not
 // throughput-bound.  force_bt: 0 = choose, 64 / 128 = as given (tests).
@@ -624,6 +669,8 @@ inline hipError_t launch_gemm(hipStream_t st, GemmArgs g, bool akm, bool bkm, in
   const int tm = g.M / TILE, tn = g.N / TILE;
   const long long blocks128 = (long long)(g.lower_only ? tm * (tm + 1) / 2 : tm * tn) * batch;
   const bool small = force_bt ? (force_bt == 64) : (blocks128 < g_small_launch_blocks);
+  if ((force_bt == 12864 || (!force_bt && small && g_rect_min_blocks > 0 && blocks128 >= g_rect_min_blocks)) && !(reserve && ctr))
+    return launch_gemm_rect<T>(st, g, akm, bkm, batch);
   if (small && !(reserve && ctr)) return launch_gemm_bt<T, 64, 4>(st, g, akm, bkm, batch);
   return launch_gemm_bt<T, 128, 4>(st, g, akm, bkm, batch, ctr, ctr ? reserve : nullptr);
 }
@@ -631,7 +678,8 @@ inline hipError_t launch_gemm(hipStream_t st, GemmArgs g, bool akm, bool bkm, in
 // true when launch_gemm would run g as a plain 64-tile launch (the precondition of the dual launch)
 inline bool gemm_is_small(const GemmArgs& g, int batch) {
   const int tm = g.M / TILE, tn = g.N / TILE;
-  return (long long)(g.lower_only ? tm * (tm + 1) / 2 : tm * tn) * batch < g_small_launch_blocks;
+  const long long b = (long long)(g.lower_only ? tm * (tm + 1) / 2 : tm * tn) * batch;
+  return b < g_small_launch_blocks && !(g_rect_min_blocks > 0 && b >= g_rect_min_blocks);
 }
 // g1: m-major x m-major (syrk), g2: m-major x k-major (U = T21 W11), both as 64-tile launches in one grid
 template <typename T>

@@ -1244,6 +1244,7 @@ struct Pipe {
     // be placed stay pending in the dispatcher, and a dispatch with pending workgroups kept the YOUNGER leaf launch from
     // starting at all (measured: an oversized grid drained only through the shader engine that holds the reserved CU,
     // 24 of 80 surplus workgroups; the leaf servers started 12 us after the workers had given up).
+    d.leaf_servers = c->dag_leaf_blocks >= 0 ? std::max(1, std::min(c->dag_leaf_blocks > 0 ? c->dag_leaf_blocks : std::min(n, 8), 8)) : 0;
     hipLaunchKernelGGL((dag_worker_kernel<T>), dim3(gpc::g_block_slots), dim3(256), 0, sd, d);
     if (mode == MODE_GRAD && with_lauum) {
       HIPCHK(c, hipEventRecord(c->ev_l1[gidx], sd));
@@ -2484,7 +2485,7 @@ int debug_gemm_impl(gpc_ctx* c, int M, int N, int K, int akm, int bkm, double al
   g.khi = khi;
   g.lower_only = lower & 1;
   g.tiles_n = N / TILE;
-  HIPCHK(c, launch_gemm<T>(c->st, g, akm != 0, bkm != 0, 1, (lower & 0x100) ? 64 : ((lower & 0x200) ? 128 : 0)));
+  HIPCHK(c, launch_gemm<T>(c->st, g, akm != 0, bkm != 0, 1, (lower & 0x100) ? 64 : ((lower & 0x200) ? 128 : ((lower & 0x400) ? 12864 : 0))));
   return download_as<T>(c, c->dbg3.as<T>(), C, (size_t)M * N);
 }
 
@@ -2806,6 +2807,7 @@ int gpc_create(int device, gpc_ctx** out) {
   if (const char* e = getenv("GPC_NLL_BLOCK")) c->nll_block = atoi(e) < 0 ? -1 : (atoi(e) == 0 ? 0 : std::max(TILE, (atoi(e) / TILE) * TILE));
   if (const char* e = getenv("GPC_GROUPS")) c->groups = std::max(1, std::min((int)gpc_ctx::MAXG, atoi(e)));
   if (const char* e = getenv("GPC_SMALL_BLOCKS")) gpc::g_small_launch_blocks = atoi(e);
+  if (const char* e = getenv("GPC_RECT_MIN")) gpc::g_rect_min_blocks = atoi(e);
   if (const char* e = getenv("GPC_DUAL")) gpc::g_dual_launch = atoi(e) != 0;
   if (const char* e = getenv("GPC_GEMM_FLAGS")) gpc::g_gemm_flags = atoi(e);
   if (const char* e = getenv("GPC_XCD_AFFINE")) gpc::g_gemm_flags = atoi(e) ? (gpc::g_gemm_flags | 8) : (gpc::g_gemm_flags & ~8);
@@ -3282,6 +3284,8 @@ int gpc_set_option(gpc_ctx* c, const char* name, int value) {
     c->groups = std::max(1, std::min((int)gpc_ctx::MAXG, value));
   else if (n == "small_blocks")
     gpc::g_small_launch_blocks = value;
+  else if (n == "rect_min")  // launches of at least this many 128-tiles (x samples) below the 128-tile threshold run as 128 x 64 tiles (0: off)
+    gpc::g_rect_min_blocks = value;
   else if (n == "dual_launch")  // syrk + inverse product of a node in one launch (default 1)
     gpc::g_dual_launch = value != 0;
   else if (n == "leaf")  // 5: pipelined leaf (default), 3: barrier-per-phase leaf (A/B and bit-identity tests)
@@ -3351,6 +3355,7 @@ int gpc_get_option(gpc_ctx* c, const char* name, int* value) {
   else if (n == "stable") *value = c->stable;
   else if (n == "small_path") *value = c->small_path;
   else if (n == "check_queues") *value = c->check_queues;
+  else if (n == "rect_min") *value = gpc::g_rect_min_blocks;
   else if (n == "dag") *value = c->dag;
   else if (n == "dag_small_tiles") *value = c->dag_small_tiles;
   else if (n == "dag_lauum") *value = c->dag_lauum;

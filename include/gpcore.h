@@ -216,7 +216,7 @@ int gpc_mfma_peak(gpc_ctx* ctx, int dtype, double* tflops, double* cycles_per_mf
  * C[M x N] = beta*C + alpha*op(A)op(B) with the library's tiled MFMA GEMM.
  * a_kmajor: A stored K x M (else M x K); b_kmajor: B stored K x N (else N x K).
  * M, N, K multiples of 128.  klo/khi/lower_only: per-tile k-range modes (see
- * gpyreg_amd/csrc/gemm.h); lower_only bit 0 = lower tiles only, 0x100 / 0x200 force
+ * gpyreg_amd/csrc/gemm.h); lower_only bit 0 = lower tiles only, 0x400 forces the 128 x 64 tile, 0x100 / 0x200 force
  * the 64- / 128-tile kernel variant.                                               */
 int gpc_debug_gemm(gpc_ctx* ctx, int dtype, int M, int N, int K, int a_kmajor,
                    int b_kmajor, double alpha, int beta, int klo, int khi,

@@ -65,6 +65,41 @@ def test_gemm_modes_fp64(ctx, bt, akm, bkm, M, N, K, klo, khi, lower, alpha, bet
         assert np.array_equal(got[~mask], C0[~mask])
 
 
+@pytest.mark.parametrize("akm,bkm", [(0, 0), (0, 1), (1, 1), (1, 0)])
+@pytest.mark.parametrize(
+    "M,N,K,klo,khi,lower,alpha,beta",
+    [
+        (128, 128, 128, 0, 0, 0, 1.0, 0),
+        (256, 384, 128, 0, 0, 0, -1.0, 1),
+        (384, 384, 384, 0, 0, 1, -1.0, 1),
+        (384, 256, 256, 0, 2, 0, 1.0, 0),
+        (256, 384, 384, 2, 0, 0, 1.0, 0),
+        (384, 256, 384, 0, 1, 0, -1.0, 0),
+        (640, 640, 640, 1, 0, 1, 1.0, 0),
+    ],
+)
+def test_rectangular_tile_gives_the_bits_of_the_square_tiles(ctx, akm, bkm, M, N, K, klo, khi, lower, alpha, beta):
+    """The 128 x 64 tile (gemm.h: BTN; round 5) against the 64-tile launch of the same product: every element keeps its
+    k-range and k-order, so the results are identical bit for bit -- fp64 and fp32, every operand orientation, every
+    k-range mode, lower-only launches (where the rectangular launch covers the 64-tile launch's tiles and, above the
+    diagonal of a 128-row block, one 64-tile more per row of tiles: compared on the 64-tile launch's tiles)."""
+    from gpyreg_amd import _lib
+
+    rng = np.random.default_rng(M + 3 * N + 7 * K + 11 * klo + 13 * khi + akm * 17 + bkm * 19 + 23)
+    A = rng.standard_normal((K, M) if akm else (M, K))
+    B = rng.standard_normal((K, N) if bkm else (N, K))
+    C0 = rng.standard_normal((M, N))
+    for dtype in (_lib.F64, _lib.F32):
+        sq = ctx.debug_gemm(A, B, C0, M, N, K, akm, bkm, alpha, beta, klo, khi, lower, dtype=dtype, force_bt=64)
+        rc = ctx.debug_gemm(A, B, C0, M, N, K, akm, bkm, alpha, beta, klo, khi, lower, dtype=dtype, force_bt=12864)
+        mask = np.ones((M, N), bool)
+        if lower:
+            for ti in range(M // 64):
+                for tj in range(ti + 1, N // 64):
+                    mask[ti * 64:(ti + 1) * 64, tj * 64:(tj + 1) * 64] = False
+        assert np.array_equal(sq[mask], rc[mask]), (dtype, np.abs(sq - rc)[mask].max())
+
+
 def test_gemm_fp32(ctx):
     from gpyreg_amd import _lib
 
