@@ -93,6 +93,9 @@ struct DagDev {  // kernel argument
   int ring_base[DAG_NRINGS];  // offset of each ring in `slots`
   int ntasks, S, nteams;
   int leaf_servers;     // leaf servers launched beside the workers (0: none -- the test hook)
+  int urgent_cus;       // > 0: on the XCD that serves a team's urgent ring, the workgroups on CUs with CU_ID < urgent_cus (per
+                        // shader engine) serve ONLY that ring, and no other workgroup serves it: chain tiles get CUs without a
+                        // bulk neighbour (0: every workgroup of the XCD serves urgent, crit and bulk)
   int gate, gate_task;  // samples s >= gate start when sample s - gate has finished task gate_task (0: all start at once)
   // leaf arguments
   void* A;
@@ -371,7 +374,7 @@ __device__ __forceinline__ void dag_push(const DagDev& d, int s, int t) {
 // first in the successor list that is not a leaf (the list is sorted by priority) -- instead of sending it through a
 // ring: the continuation of a chain costs no push, no poll and no pop.  Returns its entry (s * ntasks + t) or -1;
 // valid in every lane of wave 0.
-__device__ __forceinline__ int dag_complete(const DagDev& d, int s, int t, bool keep) {
+__device__ __forceinline__ int dag_complete(const DagDev& d, int s, int t, int keep) {
   const int lane = threadIdx.x & 63;
   const DagTask tk = d.tasks[t];
   int kept = -1;
@@ -382,7 +385,7 @@ __device__ __forceinline__ int dag_complete(const DagDev& d, int s, int t, bool 
       t2 = d.succ[tk.succ_begin + i];
       const int old = __hip_atomic_fetch_sub(d.pending + (size_t)s * d.ntasks + t2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       ready = old == 1;
-      mine = ready && keep && d.tasks[t2].ring != DAG_RING_LEAF;
+      mine = ready && keep && (keep == 2 ? d.tasks[t2].ring == DAG_RING_URGENT : d.tasks[t2].ring != DAG_RING_LEAF);
     }
     if (kept < 0) {
       const unsigned long long m = __ballot(mine);
@@ -415,14 +418,14 @@ __device__ __forceinline__ int dag_complete(const DagDev& d, int s, int t, bool 
 __device__ __forceinline__ int dag_pop(const DagDev& d, int urgent, int home, bool steal) {
   const int lane = threadIdx.x & 63;
   const long long t0 = wall_clock64();
-  const int crit = steal ? home - DAG_RING_BULK0 + DAG_RING_CRIT0 : -1;  // (GEMM workers; a leaf server has its one ring)
+  const int crit = steal ? home - DAG_RING_BULK0 + DAG_RING_CRIT0 : -1;  // (GEMM workers; a leaf server / a chain-only worker has its one ring)
   int idle = 0;
   for (;;) {
     const bool wide = steal && (idle & 7) == 7;
     // lane r < DAG_NRINGS: (head, tail) of ring r -- only the lanes of the rings looked at in this round load;
     // lanes DAG_NRINGS, DAG_NRINGS + 1: the two status words
     int h = 0, tl = 0;
-    const bool look = lane == urgent || lane == crit || lane == home ||
+    const bool look = (urgent >= 0 && lane == urgent) || (crit >= 0 && lane == crit) || (home >= 0 && lane == home) ||
                       (wide && lane >= DAG_RING_CRIT0 && lane < DAG_RING_LEAF && (lane - DAG_RING_CRIT0) % NQ < d.nteams);
     if (look) {
       const unsigned long long v = __hip_atomic_load(&d.ctl->ring[lane].ht, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -442,7 +445,7 @@ __device__ __forceinline__ int dag_pop(const DagDev& d, int urgent, int home, bo
         ring = urgent;
       else if (crit >= 0 && ((ne >> crit) & 1ull))
         ring = crit;
-      else if ((ne >> home) & 1ull)
+      else if (home >= 0 && ((ne >> home) & 1ull))
         ring = home;
       else {
         // another team's rings: its crit ring before any bulk ring; the search starts behind the own team, so that
@@ -526,8 +529,18 @@ __global__ __launch_bounds__(256, 2) void dag_worker_kernel(DagDev d) {
   unsigned xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   const int x = (int)(xcc & (NQ - 1));
-  const int urgent = x < d.nteams ? DAG_RING_URGENT + x : -1;
+  int urgent = x < d.nteams ? DAG_RING_URGENT + x : -1;
   const int home = DAG_RING_BULK0 + x % d.nteams;
+  bool bulk_too = true;
+  if (d.urgent_cus > 0 && urgent >= 0) {
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    const bool chain_cu = (int)((hw >> 8) & 0xf) < d.urgent_cus;
+    if (chain_cu)
+      bulk_too = false;  // this workgroup serves the urgent ring only
+    else
+      urgent = -1;       // and the others leave it alone
+  }
   if (threadIdx.x == 0) atomicCAS(&d.ctl->pad[1], 0, (int)(wall_clock64() / 100));
   int kept = -1;  // (wave 0) the task this workgroup made ready and keeps for itself
   long long c_pop = 0, c_acq = 0, c_exec = 0, c_done = 0, n_task = 0, n_kept = 0;
@@ -536,7 +549,7 @@ __global__ __launch_bounds__(256, 2) void dag_worker_kernel(DagDev d) {
     long long c0 = wall_clock64();
     if (threadIdx.x < 64) {
       n_kept += kept >= 0;
-      const int e = kept >= 0 ? kept : dag_pop(d, urgent, home, true);
+      const int e = kept >= 0 ? kept : dag_pop(d, urgent, bulk_too ? home : -1, bulk_too);
       c_pop += wall_clock64() - c0;
       c0 = wall_clock64();
       if (d.trace && threadIdx.x == 0 && e >= 0 && e / d.ntasks == 0) d.trace[(size_t)(e % d.ntasks) * 6 + 2] = c0;
@@ -589,7 +602,7 @@ __global__ __launch_bounds__(256, 2) void dag_worker_kernel(DagDev d) {
     c_exec += wall_clock64() - c0;
     c0 = wall_clock64();
     if (d.trace && threadIdx.x == 0 && s == 0) d.trace[(size_t)t * 6 + 3] = c0;
-    if (threadIdx.x < 64) kept = dag_complete(d, s, t, true);
+    if (threadIdx.x < 64) kept = dag_complete(d, s, t, bulk_too ? 1 : 2);
     c_done += wall_clock64() - c0;
     if (d.trace && threadIdx.x == 0 && s == 0) d.trace[(size_t)t * 6 + 4] = wall_clock64();
   }
@@ -640,7 +653,7 @@ __global__ __launch_bounds__(256, 1) void dag_leaf_kernel(DagDev d, int fault) {
     if (threadIdx.x < 64) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      (void)dag_complete(d, s, t, false);
+      (void)dag_complete(d, s, t, 0);
       if (d.trace && threadIdx.x == 0 && s == 0) d.trace[(size_t)t * 6 + 4] = wall_clock64();
     }
   }

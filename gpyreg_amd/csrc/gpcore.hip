@@ -523,6 +523,7 @@ struct gpc_ctx {
   int dag_leaf_blocks = 0;   // leaf servers; 0: min(samples, 8)
   int dag_gate = 0;          // > 0: sample s starts when sample s - dag_gate has finished the leaf at dag_gate_pct % of its chain
   int dag_gate_pct = 50;
+  int dag_urgent_cus = 0;    // > 0: CUs per shader engine (on a team's urgent XCD) whose workgroups serve the urgent ring only
   int dag_crit_pct = 15;     // tasks with less slack than this share of the critical path go to the urgent / crit rings
   int dag_timeout_ms = 2000; // a workgroup that finds nothing to do for this long aborts the graph
   int dag_runs = 0, dag_aborts = 0;  // statistics (gpc_get_option "dag_runs" / "dag_aborts")
@@ -1244,6 +1245,7 @@ struct Pipe {
     // be placed stay pending in the dispatcher, and a dispatch with pending workgroups kept the YOUNGER leaf launch from
     // starting at all (measured: an oversized grid drained only through the shader engine that holds the reserved CU,
     // 24 of 80 surplus workgroups; the leaf servers started 12 us after the workers had given up).
+    d.urgent_cus = c->dag_urgent_cus;
     d.leaf_servers = c->dag_leaf_blocks >= 0 ? std::max(1, std::min(c->dag_leaf_blocks > 0 ? c->dag_leaf_blocks : std::min(n, 8), 8)) : 0;
     hipLaunchKernelGGL((dag_worker_kernel<T>), dim3(gpc::g_block_slots), dim3(256), 0, sd, d);
     if (mode == MODE_GRAD && with_lauum) {
@@ -3319,6 +3321,8 @@ int gpc_set_option(gpc_ctx* c, const char* name, int value) {
     c->dag_leaf_blocks = value;
   else if (n == "dag_aborts")  // (tests: forget earlier aborts -- three of them switch the graph off for the context)
     c->dag_aborts = value;
+  else if (n == "dag_urgent_cus")
+    c->dag_urgent_cus = std::max(0, std::min(15, value));
   else if (n == "dag_gate")
     c->dag_gate = value;
   else if (n == "dag_gate_pct")
@@ -3361,6 +3365,7 @@ int gpc_get_option(gpc_ctx* c, const char* name, int* value) {
   else if (n == "dag_lauum") *value = c->dag_lauum;
   else if (n == "dag_leaf_blocks") *value = c->dag_leaf_blocks;
   else if (n == "dag_gate") *value = c->dag_gate;
+  else if (n == "dag_urgent_cus") *value = c->dag_urgent_cus;
   else if (n == "dag_gate_pct") *value = c->dag_gate_pct;
   else if (n == "dag_crit_pct") *value = c->dag_crit_pct;
   else if (n == "dag_timeout_ms") *value = c->dag_timeout_ms;
