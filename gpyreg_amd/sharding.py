@@ -72,7 +72,7 @@ def _buffers(maxrows, C, world, dev):
         _pool_bytes[0] -= _set_bytes(key)
         return key, free.pop()
     cuda = dev.type == "cuda"
-    buf = torch.zeros((maxrows, C), dtype=torch.float64, device=dev)
+    buf = torch.empty((maxrows, C), dtype=torch.float64, device=dev)  # (every exchange writes the whole block)
     out = torch.empty((world * maxrows, C), dtype=torch.float64, device=dev)
     hin = torch.zeros((maxrows, C), dtype=torch.float64, pin_memory=cuda) if cuda else None
     hout = torch.empty((world * maxrows, C), dtype=torch.float64, pin_memory=cuda) if cuda else None
@@ -120,11 +120,20 @@ class _Gather:
         dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
         self.key, self.bufs = _buffers(self.maxrows, C, self.world, dev)  # held until the collective has completed
         buf, out, hin, hout, vin, vout = self.bufs
+        self.direct = None
         try:
             n = local.shape[0]
             vin[:n] = local
             if n < self.maxrows:
                 vin[n:] = 0.0
+            if hin is not None:
+                from . import _rccl
+
+                self.direct = _rccl.comm_for(group)  # GPYREG_AMD_EXCHANGE=rccl: one direct RCCL call, no torch collective
+            if self.direct is not None:
+                self.direct.issue(hin, buf, out, hout)
+                self.work = None
+                return
             if hin is not None:  # device group: through the pinned image, asynchronously on the current stream
                 buf.copy_(hin, non_blocking=True)
             self.work = dist.all_gather_into_tensor(out, buf, group=group, async_op=True)
@@ -137,10 +146,13 @@ class _Gather:
 
         buf, out, hin, hout, vin, vout = self.bufs
         try:
-            self.work.wait()
-            if hout is not None:
-                hout.copy_(out, non_blocking=True)
-                torch.cuda.current_stream().synchronize()
+            if self.direct is not None:
+                self.direct.wait()  # upload, all-gather and download were enqueued together
+            else:
+                self.work.wait()
+                if hout is not None:
+                    hout.copy_(out, non_blocking=True)
+                    torch.cuda.current_stream().synchronize()
             full = vout.reshape(self.world, self.maxrows, -1)
             if self.raw:
                 return full.copy()

@@ -148,6 +148,36 @@ def test_the_rccl_branch_with_one_rank():
     assert p.returncode == 0 and "gather ok" in p.stdout, p.stderr[-3000:]
 
 
+@pytest.mark.gpu
+def test_direct_rccl_exchange_one_rank():
+    """GPYREG_AMD_EXCHANGE=rccl (optional, off by default): the exchange as ONE direct `ncclAllGather` through ctypes on a
+    communicator made from the process group (gpyreg_amd/_rccl.py) -- the same rows as the torch.distributed exchange, buffers
+    reused across many gathers of several shapes, and the frame of `gather_rows`."""
+    import socket
+
+    code = (
+        "import os, sys, numpy as np, torch, torch.distributed as dist\n"
+        "sys.path.insert(0, %r)\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', device_id=torch.device('cuda', 0))\n"
+        "from gpyreg_amd import sharding as sh, _rccl\n"
+        "rng = np.random.default_rng(3)\n"
+        "for k in range(40):\n"
+        "    rows, cols = [(1, 512), (4, 3), (2, 15), (16, 2001)][k %% 4]\n"
+        "    a = rng.standard_normal((rows, cols))\n"
+        "    g = sh._Gather(a, rows)\n"
+        "    assert g.direct is not None and np.array_equal(g.result(), a), k\n"
+        "assert not _rccl._state['failed'] and len(_rccl._state['comms']) == 1\n"
+        "dist.barrier(); dist.destroy_process_group(); print('direct gather ok')\n" % ROOT)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    e = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+             HSA_ENABLE_IPC_MODE_LEGACY="0", GPYREG_AMD_EXCHANGE="rccl")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=e, cwd=ROOT)
+    assert p.returncode == 0 and "direct gather ok" in p.stdout, p.stderr[-3000:]
+
+
 def test_under_torch_distributed_run_exactly_as_the_driver_launches_it():
     """`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
     --gpus N ...` (the multi-GPU command of the bench contract), here with --dry-run: no second launch of ranks, the

@@ -15,6 +15,7 @@ torch.cuda.set_device(0)
 dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
 from gpyreg_amd import sharding as sh
 
+print("exchange:", os.environ.get("GPYREG_AMD_EXCHANGE", "torch"), "(GPYREG_AMD_EXCHANGE=rccl: one direct ncclAllGather through ctypes)")
 print(f"frame = 1 x {sh.FRAME} doubles per rank: the ONE gather of a sharded call whose rows fit in it (round 5)")
 for rows, cols in ((1, sh.FRAME), (1, 3), (2, 15), (8, 15), (16, 2001)):
     a = np.random.default_rng(0).standard_normal((rows, cols))
