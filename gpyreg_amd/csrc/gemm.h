@@ -655,8 +655,34 @@ inline hipError_t launch_gemm_rect(hipStream_t st, GemmArgs g, bool akm, bool bk
     hipLaunchKernelGGL((gemm_kernel<T, true, false, BT, 4, 0, BTN>), grid, block, 0, st, g);
   return hipGetLastError();
 }
+// 128 x 128 tiles with EIGHT waves (2 x 4 waves of 64 x 32; plain launches): the 128-tile's operand traffic per flop at the
+// 64-tile kernel's four waves per SIMD -- tried for the same launches as the rectangular tile (g_rect_mode = 1)
+template <typename T>
+inline hipError_t launch_gemm_w8(hipStream_t st, GemmArgs g, bool akm, bool bkm, int batch) {
+  constexpr int BT = 128;
+  g.tiles_m = g.M / BT;
+  g.tiles_n = g.N / BT;
+  g.flags = g_gemm_flags;
+  const int ntiles = g.lower_only ? g.tiles_m * (g.tiles_m + 1) / 2 : g.tiles_m * g.tiles_n;
+  if (ntiles <= 0 || batch <= 0) return hipSuccess;
+  g.ntiles = ntiles;
+  g.batch = batch;
+  g.ctr = nullptr;
+  g.rsv = nullptr;
+  dim3 grid(ntiles, batch), block(512);
+  if (!akm && !bkm)
+    hipLaunchKernelGGL((gemm_kernel<T, false, false, BT, 8>), grid, block, 0, st, g);
+  else if (!akm && bkm)
+    hipLaunchKernelGGL((gemm_kernel<T, false, true, BT, 8>), grid, block, 0, st, g);
+  else if (akm && bkm)
+    hipLaunchKernelGGL((gemm_kernel<T, true, true, BT, 8>), grid, block, 0, st, g);
+  else
+    hipLaunchKernelGGL((gemm_kernel<T, true, false, BT, 8>), grid, block, 0, st, g);
+  return hipGetLastError();
+}
 // launches of at least this many 128-tiles (times samples) that are still "small" take the rectangular tile; 0: never
 inline int g_rect_min_blocks = 0;  // tunable: gpc_set_option("rect_min", n) / GPC_RECT_MIN
+inline int g_rect_mode = 0;        // 0: 128 x 64 tiles of four waves; 1: 128 x 128 tiles of eight waves ("rect_mode")
 
 // Launches that cannot put ~2 blocks of 128-tiles on every CU use 64-tiles (4x the blocks,
 // a quarter of the work each): the deep levels of the recursion are latency-, not
@@ -670,7 +696,7 @@ inline hipError_t launch_gemm(hipStream_t st, GemmArgs g, bool akm, bool bkm, in
   const long long blocks128 = (long long)(g.lower_only ? tm * (tm + 1) / 2 : tm * tn) * batch;
   const bool small = force_bt ? (force_bt == 64) : (blocks128 < g_small_launch_blocks);
   if ((force_bt == 12864 || (!force_bt && small && g_rect_min_blocks > 0 && blocks128 >= g_rect_min_blocks)) && !(reserve && ctr))
-    return launch_gemm_rect<T>(st, g, akm, bkm, batch);
+    return (g_rect_mode == 1 && force_bt != 12864) ? launch_gemm_w8<T>(st, g, akm, bkm, batch) : launch_gemm_rect<T>(st, g, akm, bkm, batch);
   if (small && !(reserve && ctr)) return launch_gemm_bt<T, 64, 4>(st, g, akm, bkm, batch);
   return launch_gemm_bt<T, 128, 4>(st, g, akm, bkm, batch, ctr, ctr ? reserve : nullptr);
 }

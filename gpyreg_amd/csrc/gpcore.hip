@@ -3288,6 +3288,8 @@ int gpc_set_option(gpc_ctx* c, const char* name, int value) {
     gpc::g_small_launch_blocks = value;
   else if (n == "rect_min")  // launches of at least this many 128-tiles (x samples) below the 128-tile threshold run as 128 x 64 tiles (0: off)
     gpc::g_rect_min_blocks = value;
+  else if (n == "rect_mode")  // what "rect_min" selects: 0 = 128 x 64 tiles of four waves, 1 = 128 x 128 tiles of eight waves
+    gpc::g_rect_mode = value != 0;
   else if (n == "dual_launch")  // syrk + inverse product of a node in one launch (default 1)
     gpc::g_dual_launch = value != 0;
   else if (n == "leaf")  // 5: pipelined leaf (default), 3: barrier-per-phase leaf (A/B and bit-identity tests)
@@ -3360,6 +3362,7 @@ int gpc_get_option(gpc_ctx* c, const char* name, int* value) {
   else if (n == "small_path") *value = c->small_path;
   else if (n == "check_queues") *value = c->check_queues;
   else if (n == "rect_min") *value = gpc::g_rect_min_blocks;
+  else if (n == "rect_mode") *value = gpc::g_rect_mode;
   else if (n == "dag") *value = c->dag;
   else if (n == "dag_small_tiles") *value = c->dag_small_tiles;
   else if (n == "dag_lauum") *value = c->dag_lauum;

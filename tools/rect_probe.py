@@ -7,6 +7,7 @@ import bench
 from gpyreg_amd import _lib
 
 N, S, grad = int(sys.argv[1]), int(sys.argv[2]), bool(int(sys.argv[3]))
+mode = int(os.environ.get("RECT_MODE", "0"))
 mins = [int(v) for v in sys.argv[4:]] or [64, 128, 256, 512]
 ctx = _lib.context(0)
 bench.CONFIGS[3] = dict(bench.CONFIGS[3], N=N)
@@ -25,8 +26,10 @@ def timed(reps=7):
     return out, min(ts), float(np.median(ts))
 
 
+ctx.set_option("rect_mode", mode)
 ctx.set_option("rect_min", 0)
 ref, a, b = timed()
+print(f"(rect_mode {mode}: {'128 x 128 tiles of eight waves' if mode else '128 x 64 tiles'})")
 print(f"N={N} S={S} grad={int(grad)}  64-tiles only      : min {a:8.3f} median {b:8.3f} ms", flush=True)
 for m in mins:
     ctx.set_option("rect_min", m)
