@@ -106,7 +106,7 @@ struct DagDev {  // kernel argument
   int* info;
   const unsigned short* rsv;
   long long timeout_ticks;
-  long long* trace;  // debug (GPC_DAG_TRACE): per task of sample 0 [ready, popped, started, ended, completed] wall-clock ticks, worker
+  long long* trace;  // debug (GPC_DAG_TRACE): per (sample, task) [ready, started, popped, ended, completed] wall-clock ticks, worker
 };
 
 // ---------------------------------------------------------------------------------------------------- host: the graph
@@ -361,7 +361,7 @@ __device__ __forceinline__ int dag_ld(const int* p) { return __hip_atomic_load(p
 
 // Push task (s, t): entry = s * ntasks + t + 1 (0 = slot not yet written).
 __device__ __forceinline__ void dag_push(const DagDev& d, int s, int t) {
-  if (d.trace && s == 0) d.trace[(size_t)t * 6 + 0] = wall_clock64();
+  if (d.trace) d.trace[((size_t)s * d.ntasks + t) * 6 + 0] = wall_clock64();
   int ring = d.tasks[t].ring;
   if (ring != DAG_RING_LEAF) ring += s % d.nteams;
   const int pos = __hip_atomic_fetch_add(d.ctl->ring[ring].tail(), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -394,7 +394,7 @@ __device__ __forceinline__ int dag_complete(const DagDev& d, int s, int t, int k
         kept = __shfl(t2, src, 64);
         if (lane == src) {
           ready = 0;  // (not pushed)
-          if (d.trace && s == 0) d.trace[(size_t)t2 * 6 + 0] = -wall_clock64();  // negative: kept, not pushed
+          if (d.trace) d.trace[((size_t)s * d.ntasks + t2) * 6 + 0] = -wall_clock64();  // negative: kept, not pushed
         }
       }
     }
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(256, 2) void dag_worker_kernel(DagDev d) {
       const int e = kept >= 0 ? kept : dag_pop(d, urgent, bulk_too ? home : -1, bulk_too);
       c_pop += wall_clock64() - c0;
       c0 = wall_clock64();
-      if (d.trace && threadIdx.x == 0 && e >= 0 && e / d.ntasks == 0) d.trace[(size_t)(e % d.ntasks) * 6 + 2] = c0;
+      if (d.trace && threadIdx.x == 0 && e >= 0) d.trace[(size_t)e * 6 + 2] = c0;
       // ONE agent-scope acquire for everything the predecessors stored (invalidates this CU's L1), waited for before
       // the barrier that releases the other waves
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -579,8 +579,8 @@ __global__ __launch_bounds__(256, 2) void dag_worker_kernel(DagDev d) {
     }
     c0 = wall_clock64();
     ++n_task;
-    if (d.trace && threadIdx.x == 0 && e / d.ntasks == 0) {
-      long long* tr = d.trace + (size_t)(e % d.ntasks) * 6;
+    if (d.trace && threadIdx.x == 0) {
+      long long* tr = d.trace + (size_t)e * 6;
       tr[1] = c0 - 0;  // popped + acquired + both barriers passed
       tr[5] = (long long)blockIdx.x | ((long long)x << 32);
     }
@@ -601,10 +601,10 @@ __global__ __launch_bounds__(256, 2) void dag_worker_kernel(DagDev d) {
     __syncthreads();
     c_exec += wall_clock64() - c0;
     c0 = wall_clock64();
-    if (d.trace && threadIdx.x == 0 && s == 0) d.trace[(size_t)t * 6 + 3] = c0;
+    if (d.trace && threadIdx.x == 0) d.trace[(size_t)e * 6 + 3] = c0;
     if (threadIdx.x < 64) kept = dag_complete(d, s, t, bulk_too ? 1 : 2);
     c_done += wall_clock64() - c0;
-    if (d.trace && threadIdx.x == 0 && s == 0) d.trace[(size_t)t * 6 + 4] = wall_clock64();
+    if (d.trace && threadIdx.x == 0) d.trace[(size_t)e * 6 + 4] = wall_clock64();
   }
 }
 
@@ -637,10 +637,10 @@ __global__ __launch_bounds__(256, 1) void dag_leaf_kernel(DagDev d, int fault) {
       return;
     }
     const int s = e / d.ntasks, t = e - s * d.ntasks;
-    if (d.trace && threadIdx.x == 0 && s == 0) {
-      d.trace[(size_t)t * 6 + 1] = wall_clock64();
-      d.trace[(size_t)t * 6 + 2] = d.trace[(size_t)t * 6 + 1];
-      d.trace[(size_t)t * 6 + 5] = -1 - (long long)blockIdx.x;
+    if (d.trace && threadIdx.x == 0) {
+      d.trace[(size_t)e * 6 + 1] = wall_clock64();
+      d.trace[(size_t)e * 6 + 2] = d.trace[(size_t)e * 6 + 1];
+      d.trace[(size_t)e * 6 + 5] = -1 - (long long)blockIdx.x;
     }
     const int off = __builtin_amdgcn_readfirstlane(d.tasks[t].launch);
     T* Ab = reinterpret_cast<T*>(d.A) + (size_t)s * d.sA + (size_t)off * d.npad + off;
@@ -649,12 +649,12 @@ __global__ __launch_bounds__(256, 1) void dag_leaf_kernel(DagDev d, int fault) {
     // plain stores: every storing wave drains, the workgroup meets, one agent-scope release writes the L2 back
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (d.trace && threadIdx.x == 0 && s == 0) d.trace[(size_t)t * 6 + 3] = wall_clock64();
+    if (d.trace && threadIdx.x == 0) d.trace[(size_t)e * 6 + 3] = wall_clock64();
     if (threadIdx.x < 64) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       (void)dag_complete(d, s, t, 0);
-      if (d.trace && threadIdx.x == 0 && s == 0) d.trace[(size_t)t * 6 + 4] = wall_clock64();
+      if (d.trace && threadIdx.x == 0) d.trace[(size_t)e * 6 + 4] = wall_clock64();
     }
   }
 }

@@ -1224,10 +1224,10 @@ struct Pipe {
     d.timeout_ticks = (long long)c->dag_timeout_ms * 100000ll;  // wall_clock64: 100 MHz
     d.trace = nullptr;
     if (getenv("GPC_DAG_TRACE")) {
-      HIPCHK(c, c->dbg2.ensure((size_t)P.ntasks * 6 * sizeof(long long)));
-      HIPCHK(c, hipMemsetAsync(c->dbg2.p, 0, (size_t)P.ntasks * 6 * sizeof(long long), st));
+      HIPCHK(c, c->dbg2.ensure((size_t)n * P.ntasks * 6 * sizeof(long long)));
+      HIPCHK(c, hipMemsetAsync(c->dbg2.p, 0, (size_t)n * P.ntasks * 6 * sizeof(long long), st));
       d.trace = c->dbg2.template as<long long>();
-      dag_trace_n = P.ntasks;
+      dag_trace_n = n * P.ntasks;
     }
     HIPCHK(c, hipMemsetAsync(d.slots, 0, (size_t)off * sizeof(int), st));
     HIPCHK(c, hipMemsetAsync(d.ctl, 0, sizeof(DagCtl), st));
@@ -1721,7 +1721,7 @@ struct Pipe {
     HIPCHK(c, c->pin.flush_down(st));
     HIPCHK(c, hipStreamSynchronize(st));
     c->pin.finish();
-    if (c->dag_used && dag_trace_n > 0 && getenv("GPC_DAG_TRACE")) {  // sample 0's task times, one line per task, to the named file
+    if (c->dag_used && dag_trace_n > 0 && getenv("GPC_DAG_TRACE")) {  // every (sample, task)'s times, one line each, to the named file
       std::vector<long long> tr((size_t)dag_trace_n * 6);
       (void)hipMemcpy(tr.data(), c->dbg2.p, tr.size() * sizeof(long long), hipMemcpyDeviceToHost);
       if (FILE* f = fopen(getenv("GPC_DAG_TRACE"), "w")) {

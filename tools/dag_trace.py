@@ -29,12 +29,13 @@ for k, v in opts.items():
 ctx.set_option("dag", 1)
 for _ in range(3):
     gp.nll_batch(hyp, compute_grad=True)
-tr = np.loadtxt(path, dtype=np.int64)
+tr_all = np.loadtxt(path, dtype=np.int64)
 npad = (N + 127) // 128 * 128
 dag = dag_model.export(npad, 1, 0, int(opts.get("dag_small_tiles", 40)))
 tasks, succ = dag["tasks"], dag["succ"]
 nt = tasks.shape[0]
-assert tr.shape[0] == nt, (tr.shape, nt)
+assert tr_all.shape[0] == nt * S, (tr_all.shape, nt, S)
+tr = tr_all[:nt]  # sample 0: the critical-path analysis
 ready, start, pop, end, done, who = (tr[:, i] for i in range(1, 7))
 kept = ready < 0
 ready = np.abs(ready)
@@ -88,3 +89,22 @@ print("first hops of the path: task kind ready pop start end next-ready (us)")
 for i, t in enumerate(path_tasks[:int(os.environ.get('DAG_TRACE_HOPS', 12))]):
     nxt = us(ready[path_tasks[i + 1]]) if i + 1 < len(path_tasks) else float("nan")
     print(f"  {t:6d} {kind[t]:5s} {'kept' if kept[t] else 'ring'} {us(ready[t]):9.1f} {us(pop[t]):9.1f} {us(start[t]):9.1f} {us(end[t]):9.1f} {nxt:9.1f}  w={int(who[t]) & 0xffffffff}/x{int(who[t]) >> 32}")
+
+# occupancy of the launch over time, ALL samples: workgroups inside a task (start .. end), by kind, per time bin -- the timeline of
+# how many of the 496 GEMM workgroups (and of the leaf servers) compute at any moment
+kind_all = np.tile(kind, S)
+st_all, en_all = tr_all[:, 2], tr_all[:, 4]
+ok = (st_all > 0) & (en_all > 0)
+T0, T1 = st_all[ok].min(), en_all[ok].max()
+nb = 40
+edges = np.linspace(T0, T1, nb + 1)
+print(f"occupancy timeline, all {S} sample(s): {nb} bins of {(T1 - T0) / nb / 100.0:.0f} us; mean workgroups computing (t64 / t128 / leaf), of 496 + leaf servers")
+for b in range(nb):
+    lo, hi = edges[b], edges[b + 1]
+    row = []
+    for k in ("t64", "t128", "leaf"):
+        m = ok & (kind_all == k)
+        ov = np.clip(np.minimum(en_all[m], hi) - np.maximum(st_all[m], lo), 0, None).sum() / (hi - lo)
+        row.append(ov)
+    bar = "#" * int(round((row[0] + row[1]) / 496 * 60))
+    print(f"  {(lo - T0) / 100.0:8.0f} us  {row[0]:6.1f} {row[1]:6.1f} {row[2]:4.1f}  |{bar}")
