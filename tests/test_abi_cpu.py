@@ -285,3 +285,25 @@ def test_plugin_protocol_sweep_matches_the_reference_output():
 
     bad = [(r, m) for r, m in zip(ref, mine) if not same(r, m)]
     assert not bad, "\n".join("reference: %s\nhere:      %s" % p for p in bad[:10])
+
+
+def test_design_kernel_table_is_the_one_generated_from_the_committed_profiles():
+    """DESIGN.md section 5's per-kernel table is generated (tools/design_kernel_table.py) from the rocprofv3 summaries
+    under profiles/ so that it cannot go stale: the block between the markers must be exactly what
+    the generator prints for the newest round tag that has a kernel-stats file."""
+    import glob
+    import re
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tags = sorted(re.match(r"(r\d+)_kernel_stats_bench_cfg3_groups1\.csv", os.path.basename(f)).group(1)
+                  for f in glob.glob(os.path.join(root, "profiles", "r[0-9][0-9]_kernel_stats_bench_cfg3_groups1.csv")))
+    assert tags, "no round-tagged kernel stats under profiles/"
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "design_kernel_table.py"), tags[-1]],
+                         capture_output=True, text=True, cwd=root)
+    assert out.returncode == 0, out.stderr
+    design = open(os.path.join(root, "DESIGN.md")).read()
+    m = re.search(r"<!-- kernel-table:begin -->.*?<!-- kernel-table:end -->", design, flags=re.S)
+    assert m and m.group(0).strip() == out.stdout.strip(), "DESIGN.md section 5 is not the generator's output: run " \
+        f"python tools/design_kernel_table.py {tags[-1]} --write"
