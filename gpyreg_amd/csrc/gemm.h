@@ -605,18 +605,22 @@ inline hipError_t launch_gemm_bt(hipStream_t st, GemmArgs g, bool akm, bool bkm,
   g.batch = batch;
   g.ctr = ctr;
   const unsigned dyn = 0u;
-  const int cap = g_block_slots - g_persist_spare;
+  // block slots of the chip for this tile size: two 128-tile workgroups per CU, four 64-tile ones
+  const int cap = (BT == 128 ? g_block_slots : 2 * g_block_slots) - g_persist_spare;
   g.rsv = reserve;
-  if (ctr && BT == 128 && cap > 0 && ((long long)ntiles * batch > cap || reserve)) {
-    dim3 grid(reserve ? cap + 96 : cap), block(64 * NW);
+  if (ctr && (BT == 128 || reserve) && cap > 0 && ((long long)ntiles * batch > cap || reserve)) {
+    // reserved launches: 128-tiles keep round 2's oversized grid (its surplus drains through the reserved CUs, of which
+    // every shader engine has some); 64-tiles (round 5, independent pipelines) take the exact-fit grid -- the workgroups
+    // that land on reserved CUs return, nothing stays pending in the dispatcher
+    dim3 grid(reserve ? (BT == 128 ? cap + 96 : cap) : cap), block(64 * NW);
     if (!akm && !bkm)
-      hipLaunchKernelGGL((gemm_persist_kernel<T, false, false, 128, NW>), grid, block, dyn, st, g);
+      hipLaunchKernelGGL((gemm_persist_kernel<T, false, false, BT, NW>), grid, block, dyn, st, g);
     else if (!akm && bkm)
-      hipLaunchKernelGGL((gemm_persist_kernel<T, false, true, 128, NW>), grid, block, dyn, st, g);
+      hipLaunchKernelGGL((gemm_persist_kernel<T, false, true, BT, NW>), grid, block, dyn, st, g);
     else if (akm && bkm)
-      hipLaunchKernelGGL((gemm_persist_kernel<T, true, true, 128, NW>), grid, block, dyn, st, g);
+      hipLaunchKernelGGL((gemm_persist_kernel<T, true, true, BT, NW>), grid, block, dyn, st, g);
     else
-      hipLaunchKernelGGL((gemm_persist_kernel<T, true, false, 128, NW>), grid, block, dyn, st, g);
+      hipLaunchKernelGGL((gemm_persist_kernel<T, true, false, BT, NW>), grid, block, dyn, st, g);
     return hipGetLastError();
   }
   dim3 grid(ntiles, batch), block(64 * NW);
@@ -688,6 +692,7 @@ inline int g_rect_mode = 0;        // 0: 128 x 64 tiles of four waves; 1: 128 x 
 // a quarter of the work each): the deep levels of the recursion are latency-, not
 // throughput-bound.  force_bt: 0 = choose, 64 / 128 = as given (tests).
 inline int g_small_launch_blocks = 1100;  // tunable: GPC_SMALL_BLOCKS
+inline int g_reserved_small_bt = 128;     // tile of a RESERVED launch below that threshold: 128 (the deferred products) or 64 (independent pipelines)
 inline bool g_dual_launch = true;         // tunable: GPC_DUAL (plan.h: syrk + U of a node in one launch)
 template <typename T>
 inline hipError_t launch_gemm(hipStream_t st, GemmArgs g, bool akm, bool bkm, int batch, int force_bt = 0,
@@ -698,6 +703,7 @@ inline hipError_t launch_gemm(hipStream_t st, GemmArgs g, bool akm, bool bkm, in
   if ((force_bt == 12864 || (!force_bt && small && g_rect_min_blocks > 0 && blocks128 >= g_rect_min_blocks)) && !(reserve && ctr))
     return (g_rect_mode == 1 && force_bt != 12864) ? launch_gemm_w8<T>(st, g, akm, bkm, batch) : launch_gemm_rect<T>(st, g, akm, bkm, batch);
   if (small && !(reserve && ctr)) return launch_gemm_bt<T, 64, 4>(st, g, akm, bkm, batch);
+  if (small && g_reserved_small_bt == 64) return launch_gemm_bt<T, 64, 4>(st, g, akm, bkm, batch, ctr, reserve);
   return launch_gemm_bt<T, 128, 4>(st, g, akm, bkm, batch, ctr, ctr ? reserve : nullptr);
 }
 

@@ -538,6 +538,10 @@ struct gpc_ctx {
   unsigned long long dag_clock = 0;
   DevBuf dag_pending, dag_slots, dag_ctl, dag_launches;
   DevBuf rsv_tbl1;  // cu_reserve_bail table with ONE CU per XCD (the leaf servers' room)
+  DevBuf rsv_tbl4;  // ... with one CU per shader engine (independent pipelines)
+  // Independent pipelines for small batches of large problems (option "indep"; round 5): every sample its own stream and
+  // pipeline, every chip-filling launch CU-reserving, so that one sample's leaves and small launches run beside another's bulk
+  int indep = 0, indep_max = 4, indep_min_tiles = 64;
 };
 
 struct gpc_post {
@@ -655,6 +659,11 @@ int build_reserve_table(gpc_ctx* c) {
     }
   HIPCHK(c, c->rsv_tbl1.ensure(sizeof tbl1));
   HIPCHK(c, hipMemcpyAsync(c->rsv_tbl1.p, tbl1, sizeof tbl1, hipMemcpyHostToDevice, c->st));
+  unsigned short tbl4[64] = {};  // the highest-numbered CU of EVERY shader engine (every engine can drain its share of a grid)
+  for (int i = 0; i < 64; ++i)
+    if (c->cu_seen[i]) tbl4[i] = (unsigned short)(1u << (31 - __builtin_clz(c->cu_seen[i])));
+  HIPCHK(c, c->rsv_tbl4.ensure(sizeof tbl4));
+  HIPCHK(c, hipMemcpyAsync(c->rsv_tbl4.p, tbl4, sizeof tbl4, hipMemcpyHostToDevice, c->st));
   HIPCHK(c, hipStreamSynchronize(c->st));
   return 0;
 }
@@ -931,6 +940,11 @@ struct Pipe {
       F.defer_min = defer_node;
       F.reserve = reserve_tbl();
     }
+    if (indep_mode && !c->capturing) {
+      F.reserve = c->rsv_tbl4.template as<unsigned short>();
+      F.reserve_all = true;
+      F.reserve_min = c->indep_min_tiles;
+    }
     if (c->check_queues && !c->capturing) F.qlog = &qlog;
     if (split_build) {
       F.ev_tail = c->ev_btail[gidx];
@@ -943,7 +957,7 @@ struct Pipe {
       // (no launch of a small problem is persistent -- its largest, W^T W, has tm (tm + 1) / 2 tiles per sample --
       // and the zeroing would be a launch of its own on the critical path)
       const long long tmx = npad / TILE, biggest = tmx * (tmx + 1) / 2 * n;
-      if (defer_node > 0 || biggest >= std::min<long long>(gpc::g_small_launch_blocks, gpc::g_block_slots - gpc::g_persist_spare))
+      if (defer_node > 0 || F.reserve_all || biggest >= std::min<long long>(gpc::g_small_launch_blocks, gpc::g_block_slots - gpc::g_persist_spare))
         HIPCHK(c, hipMemsetAsync(F.ctr, 0, (gpc_ctx::CTR_PER_GROUP - CTR_STRIDE) * sizeof(int), st));
       else
         F.ctr = nullptr;
@@ -984,7 +998,7 @@ struct Pipe {
     // needs alpha.  (Eager one- or multi-group pipelines; a captured graph keeps the serial order.)
     // (fp64 only: the fp32 GEMM uses 249 VGPRs, two of its blocks leave no register for anything else)
     const bool solves_beside_lauum = mode == MODE_GRAD && !c->capturing && !kmode() && c->solves_beside_lauum &&
-                                     sizeof(T) == 8 && npad >= 2048 && gpc::g_persist_spare >= 0 && !dag_has_lauum;
+                                     sizeof(T) == 8 && npad >= 2048 && gpc::g_persist_spare >= 0 && !dag_has_lauum && !indep_mode;
     auto solves = [&](hipStream_t sx) -> int {
       const hipStream_t keep = F.st;
       F.st = sx;
@@ -1084,6 +1098,7 @@ struct Pipe {
 
   // ---- tile-level dataflow (dag.h) ----------------------------------------------------------------------------
   bool use_dag = false;  // run(): this pipeline's factorization goes through the task graph
+  bool indep_mode = false;  // run(): one pipeline per sample, chip-filling launches CU-reserving
   int dag_trace_n = 0;
   // "dag" = -1: where the graph was measured to win
   bool dag_auto(int cnt, int npad) const { return false; }
@@ -1676,6 +1691,17 @@ struct Pipe {
         groups = 1;
         defer_node = 0;
       }
+    }
+    // Independent pipelines (option "indep"): a batch of 2 .. indep_max samples of a large problem as one pipeline PER
+    // SAMPLE on its own stream, every chip-filling launch persistent and off one CU per shader engine -- the leaves and small
+    // launches of one sample then run on those CUs while another sample's products fill the rest (lock-step runs every
+    // sample's chain at the same time and nothing beside it).  Same tiles, same bits.
+    indep_mode = c->indep != 0 && !use_dag && !use_rl && !kmode() && !(stable || c->stable) && mode != MODE_POST && c->cu_map_ok &&
+                 cnt >= 2 && cnt <= c->indep_max && npad >= 2048 && gpc::g_persist_spare >= 0;
+    gpc::g_reserved_small_bt = indep_mode ? 64 : 128;
+    if (indep_mode) {
+      groups = cnt;
+      defer_node = 0;
     }
     if (groups == 1 && defer_node == 0 && !use_rl && !use_dag && c->graph_max_npad > 0 && npad <= c->graph_max_npad && !kmode()) {
       int rc = graph_section(cnt);
@@ -3288,6 +3314,12 @@ int gpc_set_option(gpc_ctx* c, const char* name, int value) {
     gpc::g_small_launch_blocks = value;
   else if (n == "rect_min")  // launches of at least this many 128-tiles (x samples) below the 128-tile threshold run as 128 x 64 tiles (0: off)
     gpc::g_rect_min_blocks = value;
+  else if (n == "indep")  // independent pipelines for batches of 2 .. indep_max samples at npad >= 2048 (0: lock-step)
+    c->indep = value;
+  else if (n == "indep_max")
+    c->indep_max = std::max(2, std::min((int)gpc_ctx::MAXG, value));
+  else if (n == "indep_min_tiles")
+    c->indep_min_tiles = std::max(1, value);
   else if (n == "rect_mode")  // what "rect_min" selects: 0 = 128 x 64 tiles of four waves, 1 = 128 x 128 tiles of eight waves
     gpc::g_rect_mode = value != 0;
   else if (n == "dual_launch")  // syrk + inverse product of a node in one launch (default 1)
@@ -3363,6 +3395,9 @@ int gpc_get_option(gpc_ctx* c, const char* name, int* value) {
   else if (n == "check_queues") *value = c->check_queues;
   else if (n == "rect_min") *value = gpc::g_rect_min_blocks;
   else if (n == "rect_mode") *value = gpc::g_rect_mode;
+  else if (n == "indep") *value = c->indep;
+  else if (n == "indep_max") *value = c->indep_max;
+  else if (n == "indep_min_tiles") *value = c->indep_min_tiles;
   else if (n == "dag") *value = c->dag;
   else if (n == "dag_small_tiles") *value = c->dag_small_tiles;
   else if (n == "dag_lauum") *value = c->dag_lauum;

@@ -69,6 +69,8 @@ struct Factor {
     int ntiles, batch;
   };
   std::vector<QueueCheck>* qlog = nullptr;
+  bool reserve_all = false;  // see gemm(): all chip-filling launches of this pipeline are CU-reserving
+  int reserve_min = 64;
   bool dual_launch = g_dual_launch;  // syrk + inverse product of a node in one launch where both are small
   // Stable mode (the jitter retries, gpcore.hip: retry_failed): the trsm-as-a-product T21 = A21 W11^T has an error of
   // cond(L11) eps instead of eps, which on a numerically singular matrix makes the factorization fail where a
@@ -147,6 +149,9 @@ struct Factor {
     // 16384 has 250-500 launches, and the big ones (which need the slots) come last in the order
     const long long tm = M / TILE, tn = N / TILE;
     const long long blocks128 = (lower ? tm * (tm + 1) / 2 : tm * tn) * batch;
+    // independent pipelines (gpcore.hip: Pipe::run, option "indep"): every launch of at least reserve_min 128-tiles stays off
+    // the reserved CUs, on THIS stream -- the other pipelines' leaves and small launches run there meanwhile
+    if (!rsv && reserve_all && reserve && blocks128 >= reserve_min) rsv = reserve;
     const bool persistent = rsv || (blocks128 >= g_small_launch_blocks && blocks128 > g_block_slots - g_persist_spare);
     if (persistent && ctr && ctr_used + CTR_STRIDE <= ctr_cap) {
       slot = ctr + ctr_used;
@@ -200,7 +205,8 @@ struct Factor {
     {
       GemmArgs gs = make_args(blk(A, o2, o2), sA, blk(Tm, o2, o1), sT, blk(Tm, o2, o1), sT, n2, n2, n1, -1.0, 1,
                               KLO_ZERO, KHI_FULL, 1);
-      if (need_inv && !defer && dual_launch && !rec && gemm_is_small(gs, batch)) {
+      const long long syrk_tiles = (long long)(n2 / TILE) * (n2 / TILE + 1) / 2 * batch;
+      if (need_inv && !defer && dual_launch && !rec && gemm_is_small(gs, batch) && !(reserve_all && syrk_tiles >= reserve_min)) {
         GemmArgs gu = make_args(blk(A, o2, o1), sA, blk(Tm, o2, o1), sT, blk(W, o1, o1), sW, n2, n1, n1, 1.0, 0,
                                 KLO_COL, KHI_FULL, 0);
         if (gemm_is_small(gu, batch)) {
