@@ -112,3 +112,29 @@ def test_non_positive_definite_sample_inside_a_graph(ctx):
     finally:
         bench.CONFIGS[3] = cfg
         ctx.set_option("dag", 0)
+
+
+def test_independent_pipelines_do_not_change_a_bit(ctx):
+    """gpc_set_option("indep", 1) (round 5, off by default: measured slower): a batch of 2-4 samples of a large problem as one
+    pipeline per sample on its own stream, the chip-filling launches persistent 64-tile launches that stay off one CU per
+    shader engine.  The same tiles in another launch form: NLL and gradient identical bit for bit (N = 2304, three
+    samples; with the reservation threshold at 64 and at 500 tiles)."""
+    import bench
+
+    cfg = dict(bench.CONFIGS[3])
+    try:
+        bench.CONFIGS[3] = dict(cfg, N=2304)
+        X, y, hyp = bench.synthetic_problem(3, 3)
+        gp = bench.make_gp(3, "f64")
+        gp.update(X_new=X, y_new=y, hyp=hyp[:1], compute_posterior=False)
+        ref = gp.nll_batch(hyp, compute_grad=True) + (gp.nll_batch(hyp, compute_grad=False)[0],)
+        for min_tiles in (64, 500):
+            ctx.set_option("indep", 1)
+            ctx.set_option("indep_min_tiles", min_tiles)
+            got = gp.nll_batch(hyp, compute_grad=True) + (gp.nll_batch(hyp, compute_grad=False)[0],)
+            for a, b in zip(ref, got):
+                assert np.array_equal(a, b), min_tiles
+    finally:
+        bench.CONFIGS[3] = cfg
+        ctx.set_option("indep", 0)
+        ctx.set_option("indep_min_tiles", 64)
