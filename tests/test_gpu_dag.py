@@ -138,3 +138,43 @@ def test_independent_pipelines_do_not_change_a_bit(ctx):
         bench.CONFIGS[3] = cfg
         ctx.set_option("indep", 0)
         ctx.set_option("indep_min_tiles", 64)
+
+
+def test_workspace_hash_debug_entry(ctx):
+    """gpc_debug_workspace_hash (include/gpcore.h): per-tile hashes of the workspace of the last call -- equal for the same
+    evaluation repeated, and the W / T tiles on and below the diagonal equal between the two schedules (the tool that found
+    the one scheduling bug of the round, tools/dag_hashdiff.py, rests on it)."""
+    import bench
+
+    cfg = dict(bench.CONFIGS[3])
+    try:
+        bench.CONFIGS[3] = dict(cfg, N=640)
+        X, y, hyp = bench.synthetic_problem(3, 2)
+        gp = bench.make_gp(3, "f64")
+        gp.update(X_new=X, y_new=y, hyp=hyp[:1], compute_posterior=False)
+        nt = 5
+
+        def hashes():
+            out = []
+            for which in range(3):
+                h = np.zeros(nt * nt, dtype=np.uint64)
+                assert ctx._lib.gpc_debug_workspace_hash(ctx._h, 0, which, 1, h.ctypes.data) == 0
+                out.append(h.reshape(nt, nt))
+            return out
+
+        gp.nll_batch(hyp, compute_grad=True)
+        a = hashes()
+        gp.nll_batch(hyp, compute_grad=True)
+        b = hashes()
+        assert all(np.array_equal(x, z) for x, z in zip(a, b))
+        ctx.set_option("dag", 1)
+        ctx.set_option("dag_aborts", 0)
+        gp.nll_batch(hyp, compute_grad=True)
+        d = hashes()
+        low = np.tril(np.ones((nt, nt), bool))
+        assert np.array_equal(a[1][low], d[1][low]) and np.array_equal(a[2][low], d[2][low])
+        gp.nll_batch(hyp + 0.01, compute_grad=True)
+        assert not np.array_equal(hashes()[1], d[1])
+    finally:
+        bench.CONFIGS[3] = cfg
+        ctx.set_option("dag", 0)
