@@ -31,7 +31,7 @@ for _ in range(3):
     gp.nll_batch(hyp, compute_grad=True)
 tr_all = np.loadtxt(path, dtype=np.int64)
 npad = (N + 127) // 128 * 128
-dag = dag_model.export(npad, 1, 0, int(opts.get("dag_small_tiles", 40)))
+dag = dag_model.export(npad, 1 if int(opts.get("dag_lauum", 1)) else 2, 0, int(opts.get("dag_small_tiles", 40)))
 tasks, succ = dag["tasks"], dag["succ"]
 nt = tasks.shape[0]
 assert tr_all.shape[0] == nt * S, (tr_all.shape, nt, S)
