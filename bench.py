@@ -49,6 +49,9 @@ CONFIGS = {
     3: dict(N=4096, D=10, kernel="matern", degree=5, S=16),
     4: dict(N=16384, D=20, kernel="rq", degree=0, S=1),
     5: dict(N=8192, D=8, kernel="se", degree=0, S=64),
+    # (not a BASELINE configuration: twice the N that the device library accepted before round 6 -- the reference
+    # factorizes whatever fits host memory, gaussian_process.py:2415-2417, :2477-2484)
+    6: dict(N=32768, D=5, kernel="se", degree=0, S=2),
 }
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X datasheet, dense fp64 matrix
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md chip table
@@ -150,12 +153,14 @@ def cpu_baseline(cfg_idx, gpu_nlz0=None, gpu_dnlz0=None, grad=True):
     import subprocess
 
     c = CONFIGS[cfg_idx]
-    # cfg2/cfg3: the full protocol.  cfg5 (N=8192): one evaluation (minutes).  cfg4
-    # (N=16384, RQ): the reference has no fp32 path and its (N,N,22) gradient tensor needs 47 GB,
-    # so the CPU figure is one fp64 NLL-only evaluation.
+    # cfg2 (0.7 s per evaluation): BASELINE.md's own protocol, 3 warm-ups + median of 10.  cfg3 (14 s): 1 warm-up +
+    # median of 3.  cfg5 (N=8192): one evaluation (minutes).  cfg4 (N=16384, RQ): the reference has no fp32 path and its
+    # (N,N,22) gradient tensor needs 47 GB, so the CPU figure is one fp64 NLL-only evaluation; cfg6
+    # (N=32768): likewise NLL only -- the (N,N,6) tensor is 52 GB on top of K, L and the inverse.
     full = cfg_idx in (2, 3)
-    grad = grad and cfg_idx != 4
-    times, (nlz, dnlz) = _oracle_eval_seconds(cfg_idx, repeats=3 if full else 1, warmup=1 if full else 0, grad=grad)
+    grad = grad and cfg_idx not in (4, 6)
+    repeats, warmup = {2: (10, 3), 3: (3, 1)}.get(cfg_idx, (1, 0))
+    times, (nlz, dnlz) = _oracle_eval_seconds(cfg_idx, repeats=repeats, warmup=warmup, grad=grad)
     med = float(np.median(times))
     if not grad:
         gpu_dnlz0 = None
@@ -175,7 +180,8 @@ def cpu_baseline(cfg_idx, gpu_nlz0=None, gpu_dnlz0=None, grad=True):
     # dominate, are single-threaded); the logical CPU count is in host.logical_cpus
     out = dict(value=1.0 / med, unit="fit-evals/s" if grad else "NLL-evals/s", cores=_blas_threads(host), kind="port",
                sample=f"sample 0 of {c['S']}, {'NLL+grad' if grad else 'NLL only (fp64)'}, N={c['N']} D={c['D']} "
-                      f"{c['kernel']}{c['degree'] or ''}: {'1 warm-up + median of 3 evaluations' if full else '1 evaluation'} "
+                      f"{c['kernel']}{c['degree'] or ''}: "
+                      f"{('%d warm-up(s) + median of %d evaluations' % (warmup, repeats)) if repeats > 1 else '1 evaluation'} "
                       f"({', '.join('%.2f' % t for t in times)} s), default BLAS threading",
                seconds_per_eval=med,
                single_thread={"value": None if one is None else 1.0 / one, "seconds_per_eval": one,
@@ -554,7 +560,7 @@ def run(args):
     # The dominant single kernel, timed ALONE as well: three extra UNTIMED steps with one sample group and the two
     # triangular mat-vecs after the launch instead of under it (they cost it ~3 %), so that its hipEvent
     # time is the kernel's own duration; the first of the three is dropped.
-    lau_alone = []
+    lau_alone, lau_alone_fl = [], 0.0
     if rank == 0 and grad and S_local > 0:
         prev = {k: ctx.get_option(k) for k in ("groups", "solves_beside_lauum")}
         ctx.set_option("groups", 1)
@@ -565,6 +571,10 @@ def run(args):
             lm, lf = ctx.last_lauum_timing()
             if lf > 0:
                 lau_alone.append(lm)
+                # the flops of THIS launch: with one sample group forced, a batch that the timed loop runs as two groups
+                # (cfg5: 2 x 32 samples) is one launch of all its samples here (dividing the timed loop's
+                # per-group flops by this launch's time read 0.45 where the launch ran at 0.90)
+                lau_alone_fl = lf
         lau_alone = lau_alone[1:]
         for k, v in prev.items():
             ctx.set_option(k, v)
@@ -699,8 +709,10 @@ def run(args):
             })
             if lau_alone:
                 la = float(np.mean(lau_alone)) * 1e-3
-                roof["alone"] = {"launch_ms": la * 1e3, "achieved": lau_fl / la / 1e12, "frac": lau_fl / la / 1e12 / peak,
-                                 "launch_ms_schedule": "untimed extra steps with the mat-vecs AFTER the launch (overlap off)"}
+                roof["alone"] = {"launch_ms": la * 1e3, "flops_per_launch": lau_alone_fl,
+                                 "achieved": lau_alone_fl / la / 1e12, "frac": lau_alone_fl / la / 1e12 / peak,
+                                 "launch_ms_schedule": "untimed extra steps with one sample group and the mat-vecs AFTER "
+                                                       "the launch (overlap off)"}
         else:
             roof.update({
                 "kernel": "blocked potrf" + (" + trtri + lauum" if grad else "") + " (gemm_kernel + leaf_kernel launches of one batch)",

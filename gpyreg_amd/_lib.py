@@ -85,8 +85,13 @@ SIGNATURES = {
     "gpc_debug_leaf": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp, _ip]),
     "gpc_debug_factor": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip]),
     "gpc_debug_workspace_hash": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp]),
+}
+# declared under GPC_EXPERIMENTS in include/gpcore.h: present in the experiments build only (lib/libgpcore_exp.so, which
+# tests/ and tools/ select through GPYREG_AMD_LIB; the product library does not export them)
+EXPERIMENT_SIGNATURES = {
     "gpc_debug_dag": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip, _dp, _ip, C.c_int, C.c_int]),
 }
+EXPERIMENTS_LIB_PATH = os.path.join(_HERE, "lib", "libgpcore_exp.so")
 
 # int (*gpc_dk_plane_fn)(void* user, int sample, int p, double* plane)
 DK_PLANE_FN = C.CFUNCTYPE(C.c_int, _vp, C.c_int, C.c_int, _dpp)
@@ -111,8 +116,18 @@ def load():
                 fn = getattr(lib, name)  # AttributeError if the .so does not export it
                 fn.restype = res
                 fn.argtypes = args
+            for name, (res, args) in EXPERIMENT_SIGNATURES.items():
+                fn = getattr(lib, name, None)
+                if fn is not None:
+                    fn.restype = res
+                    fn.argtypes = args
             _lib = lib
     return _lib
+
+
+def is_experiments_build() -> bool:
+    """True when the loaded library is the experiments build (``GPYREG_AMD_LIB=.../libgpcore_exp.so``)."""
+    return hasattr(load(), "gpc_debug_dag")
 
 
 def _f64(a):
@@ -378,7 +393,7 @@ class Context:
                    lower_only=False, dtype=F64, force_bt=0):
         A, B = _f64(A), _f64(B)
         Cm = _f64(Cm).copy()
-        flags = int(bool(lower_only)) | {0: 0, 64: 0x100, 128: 0x200, 12864: 0x400}[force_bt]
+        flags = int(bool(lower_only)) | {0: 0, 64: 0x100, 128: 0x200, 12864: 0x400}[force_bt]  # (12864: experiments build)
         rc = self._lib.gpc_debug_gemm(self._h, dtype, M, N, K, int(a_kmajor), int(b_kmajor),
                                       float(alpha), int(beta), klo, khi, flags, _ptr(A),
                                       _ptr(B), _ptr(Cm))

@@ -283,25 +283,42 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
 
   if (nk > 0) {
     vec_t ra[NVA], rb[NVB];
-    // byte offsets: per thread (fixed), per pass and per slab (block-uniform); an operand of one
-    // sample is < 4 GB for every supported size (N <= 16384 fp64)
+    // byte offsets: per thread (fixed) and per pass (block-uniform), both inside ONE k-slab of the operand (at most 128
+    // rows of an m-major image or 16 / 32 k-rows of a k-major one: megabytes).  From slab to slab an m-major operand
+    // moves by BKT elements -- a scalar offset that stays below K * sizeof(T) -- while a k-major operand moves by BKT
+    // whole rows: its 64-bit base pointer is advanced (two scalar adds) and the descriptor rebuilt, so no 32-bit byte
+    // offset ever spans a panel and the operand may be of any size (round 6; rounds 1-5 carried a 32-bit slab offset
+    // over the whole k-major panel, which capped N at 16384 in fp64).
     const unsigned toa = stage_toff<T, AKM, BT, NT>(g.lda, t) * (unsigned)sizeof(T),
                    tob = stage_toff<T, BKM, BTN, NT>(g.ldb, t) * (unsigned)sizeof(T);
     const unsigned psa = (unsigned)(stage_pstride<T, AKM, BT, NT>(g.lda) * sizeof(T)),
                    psb = (unsigned)(stage_pstride<T, BKM, BTN, NT>(g.ldb) * sizeof(T));
-    const unsigned stepa = (unsigned)((AKM ? (size_t)BKT_v<T> * g.lda : (size_t)BKT_v<T>) * sizeof(T)),
-                   stepb = (unsigned)((BKM ? (size_t)BKT_v<T> * g.ldb : (size_t)BKT_v<T>) * sizeof(T));
-    const __amdgpu_buffer_rsrc_t rsa = make_rsrc(AKM ? A + (size_t)k0 * g.lda + m0 : A + (size_t)m0 * g.lda + k0);
-    const __amdgpu_buffer_rsrc_t rsb = make_rsrc(BKM ? B + (size_t)k0 * g.ldb + n0 : B + (size_t)n0 * g.ldb + k0);
-    unsigned ua = 0, ub = 0;  // slab offsets
+    const T* pa = AKM ? A + (size_t)k0 * g.lda + m0 : A + (size_t)m0 * g.lda + k0;
+    const T* pb = BKM ? B + (size_t)k0 * g.ldb + n0 : B + (size_t)n0 * g.ldb + k0;
+    const size_t rowsa = (size_t)BKT_v<T> * g.lda, rowsb = (size_t)BKT_v<T> * g.ldb;  // elements per slab of a k-major operand
+    __amdgpu_buffer_rsrc_t rsa = make_rsrc(pa), rsb = make_rsrc(pb);
+    unsigned ua = 0, ub = 0;  // slab offsets of m-major operands (bytes)
+    auto next_slab = [&]() {
+      if constexpr (AKM) {
+        pa += rowsa;
+        rsa = make_rsrc(pa);
+      } else {
+        ua += (unsigned)(BKT_v<T> * sizeof(T));
+      }
+      if constexpr (BKM) {
+        pb += rowsb;
+        rsb = make_rsrc(pb);
+      } else {
+        ub += (unsigned)(BKT_v<T> * sizeof(T));
+      }
+    };
     constexpr int AUX = HO == 1 ? 16 : 0;  // HO = 2 (dag.h): plain loads behind the consumer's agent-scope acquire
     g2r<T, AKM, BT, NT, AUX>(ra, rsa, ua, psa, toa);
     g2r<T, BKM, BTN, NT, AUX>(rb, rsb, ub, psb, tob);
     r2s<T, AKM, BT, NT>(smem, ra, t);
     r2s<T, BKM, BTN, NT>(smem + OPSZA, rb, t);
     // slab 1 is in flight while slab 0 is multiplied (k-ranges are 128-granular: nk is a multiple of 128 / BKT >= 4)
-    ua += stepa;
-    ub += stepb;
+    next_slab();
     g2r<T, AKM, BT, NT, AUX>(ra, rsa, ua, psa, toa);
     g2r<T, BKM, BTN, NT, AUX>(rb, rsb, ub, psb, tob);
     __syncthreads();
@@ -367,8 +384,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
       __syncthreads();
       // k-step KS-1: the global loads of the slab after next between its MFMAs
       if constexpr (LD) {
-        ua += stepa;
-        ub += stepb;
+        next_slab();
         g2r<T, AKM, BT, NT, AUX>(ra, rsa, ua, psa, toa);
         g2r<T, BKM, BTN, NT, AUX>(rb, rsb, ub, psb, tob);
       }
@@ -635,6 +651,7 @@ inline hipError_t launch_gemm_bt(hipStream_t st, GemmArgs g, bool akm, bool bkm,
   return hipGetLastError();
 }
 
+#ifdef GPC_EXPERIMENTS
 // 128 x 64 tiles (plain launches): see gemm_tile's BTN
 template <typename T>
 inline hipError_t launch_gemm_rect(hipStream_t st, GemmArgs g, bool akm, bool bkm, int batch) {
@@ -688,22 +705,32 @@ inline hipError_t launch_gemm_w8(hipStream_t st, GemmArgs g, bool akm, bool bkm,
 inline int g_rect_min_blocks = 0;  // tunable: gpc_set_option("rect_min", n) / GPC_RECT_MIN
 inline int g_rect_mode = 0;        // 0: 128 x 64 tiles of four waves; 1: 128 x 128 tiles of eight waves ("rect_mode")
 
+#else
+constexpr int g_rect_min_blocks = 0;
+#endif  // GPC_EXPERIMENTS
+
 // Launches that cannot put ~2 blocks of 128-tiles on every CU use 64-tiles (4x the blocks,
 // a quarter of the work each): the deep levels of the recursion are latency-, not
 // throughput-bound.  force_bt: 0 = choose, 64 / 128 = as given (tests).
 inline int g_small_launch_blocks = 1100;  // tunable: GPC_SMALL_BLOCKS
-inline int g_reserved_small_bt = 128;     // tile of a RESERVED launch below that threshold: 128 (the deferred products) or 64 (independent pipelines)
 inline bool g_dual_launch = true;         // tunable: GPC_DUAL (plan.h: syrk + U of a node in one launch)
+// reserved_small_bt: tile of a RESERVED launch below that threshold -- 128 (the deferred products) or, experiments build
+// only, 64 (independent pipelines); carried per launch (it used to be a process-wide global that every pipeline of every
+// context wrote: contexts on different threads raced on it)
 template <typename T>
 inline hipError_t launch_gemm(hipStream_t st, GemmArgs g, bool akm, bool bkm, int batch, int force_bt = 0,
-                             int* ctr = nullptr, const unsigned short* reserve = nullptr) {
+                             int* ctr = nullptr, const unsigned short* reserve = nullptr, int reserved_small_bt = 128) {
   const int tm = g.M / TILE, tn = g.N / TILE;
   const long long blocks128 = (long long)(g.lower_only ? tm * (tm + 1) / 2 : tm * tn) * batch;
   const bool small = force_bt ? (force_bt == 64) : (blocks128 < g_small_launch_blocks);
+#ifdef GPC_EXPERIMENTS
   if ((force_bt == 12864 || (!force_bt && small && g_rect_min_blocks > 0 && blocks128 >= g_rect_min_blocks)) && !(reserve && ctr))
     return (g_rect_mode == 1 && force_bt != 12864) ? launch_gemm_w8<T>(st, g, akm, bkm, batch) : launch_gemm_rect<T>(st, g, akm, bkm, batch);
+#endif
   if (small && !(reserve && ctr)) return launch_gemm_bt<T, 64, 4>(st, g, akm, bkm, batch);
-  if (small && g_reserved_small_bt == 64) return launch_gemm_bt<T, 64, 4>(st, g, akm, bkm, batch, ctr, reserve);
+#ifdef GPC_EXPERIMENTS
+  if (small && reserved_small_bt == 64) return launch_gemm_bt<T, 64, 4>(st, g, akm, bkm, batch, ctr, reserve);
+#endif
   return launch_gemm_bt<T, 128, 4>(st, g, akm, bkm, batch, ctr, ctr ? reserve : nullptr);
 }
 

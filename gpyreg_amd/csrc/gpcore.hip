@@ -23,7 +23,13 @@
 #include "gemm.h"
 #include "leaf.h"
 #include "plan.h"
+#ifdef GPC_EXPERIMENTS
+// Schedules that were built, measured and rejected -- the tile-level dataflow graph, independent
+// per-sample pipelines, rectangular / eight-wave tiles, right-looking panels -- are compiled only into the experiments
+// build (gpyreg_amd/build.py --experiments -> lib/libgpcore_exp.so), which tests/ and tools/ opt into through
+// GPYREG_AMD_LIB.  The product library contains the shipped stream-ordered schedule and nothing else.
 #include "dag.h"
+#endif
 
 using namespace gpc;
 
@@ -430,9 +436,11 @@ struct gpc_ctx {
   // N=2048 S=1 0.96 / 1.01 / 0.98 / 0.98; N=1000 S=8 0.52 / 0.53 / 0.54 / 0.54): below npad = 2048 the round-2 scheme stays.
   int nll_block = -1;
   int solves_beside_lauum = 1;  // option: the two triangular mat-vecs of a gradient evaluation run under the W^T W launch
+#ifdef GPC_EXPERIMENTS
   // right-looking panels with look-ahead for NLL-only evaluations (plan.h: potrf_rl): panel height; 0 = off (default)
   int rl_panel = 0;
   int rl_ahead_max = 8;  // look-ahead (side stream + reserved CUs) only for batches with S (npad/4096)^3 <= this
+#endif
   int stable = 0;        // option: every factorization in stable mode (plan.h), not only the jitter retries
   int small_path = 1;    // option: problems of one 128 x 128 leaf take the two-launch pipeline (Pipe::small_section)
   int check_queues = 0;  // debug option: verify after every pipeline that the tile queues of its persistent launches were drained
@@ -514,6 +522,7 @@ struct gpc_ctx {
   double start_mult = 1.0;
   unsigned append_fail_mask = 0;
   int retry_runs = 0;  // device pipelines spent on jitter retries by the last call (one per level)
+#ifdef GPC_EXPERIMENTS
   // ---- tile-level dataflow (dag.h).  Option "dag": 0 off, 1 wherever the plan supports it, -1 automatic (by what was
   // measured to win).  The arithmetic is that of the stream-ordered schedule bit for bit, so the choice may follow the
   // batch size.
@@ -542,6 +551,7 @@ struct gpc_ctx {
   // Independent pipelines for small batches of large problems (option "indep"; round 5): every sample its own stream and
   // pipeline, every chip-filling launch CU-reserving, so that one sample's leaves and small launches run beside another's bulk
   int indep = 0, indep_max = 4, indep_min_tiles = 64;
+#endif  // GPC_EXPERIMENTS
 };
 
 struct gpc_post {
@@ -647,6 +657,7 @@ int build_reserve_table(gpc_ctx* c) {
   }
   HIPCHK(c, c->rsv_tbl.ensure(sizeof tbl));
   HIPCHK(c, hipMemcpyAsync(c->rsv_tbl.p, tbl, sizeof tbl, hipMemcpyHostToDevice, c->st));
+#ifdef GPC_EXPERIMENTS
   // the dataflow schedule (dag.h) keeps ONE CU per XCD free of GEMM workgroups for its leaf servers: the
   // highest-numbered CU of the first shader engine seen in each XCD
   unsigned short tbl1[64] = {};
@@ -664,6 +675,7 @@ int build_reserve_table(gpc_ctx* c) {
     if (c->cu_seen[i]) tbl4[i] = (unsigned short)(1u << (31 - __builtin_clz(c->cu_seen[i])));
   HIPCHK(c, c->rsv_tbl4.ensure(sizeof tbl4));
   HIPCHK(c, hipMemcpyAsync(c->rsv_tbl4.p, tbl4, sizeof tbl4, hipMemcpyHostToDevice, c->st));
+#endif
   HIPCHK(c, hipStreamSynchronize(c->st));
   return 0;
 }
@@ -940,11 +952,14 @@ struct Pipe {
       F.defer_min = defer_node;
       F.reserve = reserve_tbl();
     }
+#ifdef GPC_EXPERIMENTS
     if (indep_mode && !c->capturing) {
       F.reserve = c->rsv_tbl4.template as<unsigned short>();
+      F.reserved_small_bt = 64;
       F.reserve_all = true;
       F.reserve_min = c->indep_min_tiles;
     }
+#endif
     if (c->check_queues && !c->capturing) F.qlog = &qlog;
     if (split_build) {
       F.ev_tail = c->ev_btail[gidx];
@@ -969,6 +984,7 @@ struct Pipe {
     const bool nll_blocked = !use_rl && mode == MODE_NLL && nll_blk >= TILE && npad > nll_blk;
     bool dag_done = false, dag_has_lauum = false;
     if (nll_blocked) F.nll_block = nll_blk;  // (the blocked forward solve below reads it, whichever schedule factors)
+#ifdef GPC_EXPERIMENTS
     if (use_dag && !use_rl) {
       int rc = dag_section(st, gidx, F, nll_blocked ? nll_blk : 0, full_inv, dag_has_lauum);
       if (rc < 0) return rc;
@@ -978,12 +994,15 @@ struct Pipe {
         (void)hipStreamSynchronize(st);
       }
     }
-    if (dag_done) {
-      // (the factorization -- and W^T W when it is part of the graph -- has been issued)
-    } else if (use_rl) {
+    if (!dag_done && use_rl) {
       F.rl_panel = c->rl_panel;
       F.rl_lookahead = (double)n * std::pow((double)npad / 4096.0, 3.0) <= (double)c->rl_ahead_max;
       F.potrf_rl();
+      dag_done = true;  // (the factorization has been issued)
+    }
+#endif
+    if (dag_done) {
+      // (experiments build: the factorization -- and W^T W when it is part of the graph -- has been issued)
     } else if (nll_blocked) {
       F.nll_block = nll_blk;
       F.potrf_nll(0, npad);
@@ -1003,9 +1022,12 @@ struct Pipe {
       const hipStream_t keep = F.st;
       F.st = sx;
       F.low_regs = sx != st;
+#ifdef GPC_EXPERIMENTS
       if (use_rl)
         F.forward_solve_rl(rvec, zvec);
-      else if (nll_blocked)
+      else
+#endif
+      if (nll_blocked)
         F.forward_solve_nll(0, npad, rvec, zvec);
       else
         F.forward_solve(0, npad, full_inv, rvec, zvec);
@@ -1096,6 +1118,7 @@ struct Pipe {
     return 0;
   }
 
+#ifdef GPC_EXPERIMENTS
   // ---- tile-level dataflow (dag.h) ----------------------------------------------------------------------------
   bool use_dag = false;  // run(): this pipeline's factorization goes through the task graph
   bool indep_mode = false;  // run(): one pipeline per sample, chip-filling launches CU-reserving
@@ -1282,6 +1305,10 @@ struct Pipe {
     ++c->dag_runs;
     return 0;
   }
+#else
+  // (the product library runs the stream-ordered schedule only: the conditions below fold away)
+  static constexpr bool use_dag = false, indep_mode = false, use_rl = false;
+#endif
   // device_section through a cached launch graph (one sample group, main stream)
   int graph_section(int cnt) {
     Batch& b = *B;
@@ -1379,7 +1406,9 @@ struct Pipe {
   int chunk_s0 = 0;  // first sample (batch numbering) of the chunk being processed
   int defer_node = 0;  // plan.h: nodes at least this large run their U product on the side stream (0: none)
   bool split_build = false;
+#ifdef GPC_EXPERIMENTS
   bool use_rl = false;  // plan.h: right-looking panels with look-ahead for this pipeline
+#endif
   bool stable = false;  // plan.h: refined panel solves (jitter retries; gpc_set_option "stable")
   bool prescaled = false;  // the transfer kernel of this chunk has written the scaled inputs (run())
   std::vector<double> r_expanded;  // run(): r = y - m0 formed on the host when no pinned block was to be had
@@ -1465,7 +1494,7 @@ struct Pipe {
     memcpy(&quad[s0], hscal.data() + cnt, (size_t)cnt * 8);
     if (getenv("GPC_SCALAR_LOG"))
       for (int i = 0; i < cnt; ++i)
-        fprintf(stderr, "[gpcore] sample %d dag=%d logdet %.17g quad %.17g\n", s0 + i, (int)c->dag_used, logdet[s0 + i], quad[s0 + i]);
+        fprintf(stderr, "[gpcore] sample %d logdet %.17g quad %.17g\n", s0 + i, logdet[s0 + i], quad[s0 + i]);
     const int* hinfo = reinterpret_cast<const int*>(hscal.data() + 2 * (size_t)cnt);
     hc.lap("d2h+sync");
     for (int i = 0; i < cnt; ++i) b.info[s0 + i] = hinfo[i];
@@ -1489,6 +1518,7 @@ struct Pipe {
   // GEMMs of the other.
   // One pipeline for the samples [s0, s0 + cnt).  A dataflow graph that aborted (a bounded wait ran out: never
   // expected) is not an error of the call: the batch goes again on the stream-ordered schedule.
+#ifdef GPC_EXPERIMENTS
   static constexpr int DAG_RETRY = 77;
   bool dag_off_once = false;
   int run(int s0, int cnt, int slot) {
@@ -1502,6 +1532,9 @@ struct Pipe {
     }
     return rc;
   }
+#else
+  int run(int s0, int cnt, int slot) { return run_once(s0, cnt, slot); }
+#endif
 
   int run_once(int s0, int cnt, int slot) {
     Batch& b = *B;
@@ -1675,6 +1708,7 @@ struct Pipe {
         defer_node = (npad / 2 / TILE) * TILE;
       if (defer_node > 0) groups = 1;
     }
+#ifdef GPC_EXPERIMENTS
     // right-looking panels with look-ahead (NLL-only evaluations; side stream + CU reservation: eager)
     use_rl = mode == MODE_NLL && c->rl_panel >= TILE && npad >= 4 * c->rl_panel && !(stable || c->stable) && !kmode();
     // Launch graphs: every one-group pipeline whose schedule lives on ONE stream (the deferred products and the split
@@ -1698,11 +1732,13 @@ struct Pipe {
     // sample's chain at the same time and nothing beside it).  Same tiles, same bits.
     indep_mode = c->indep != 0 && !use_dag && !use_rl && !kmode() && !(stable || c->stable) && mode != MODE_POST && c->cu_map_ok &&
                  cnt >= 2 && cnt <= c->indep_max && npad >= 2048 && gpc::g_persist_spare >= 0;
-    gpc::g_reserved_small_bt = indep_mode ? 64 : 128;
     if (indep_mode) {
       groups = cnt;
       defer_node = 0;
     }
+#endif
+    // Launch graphs: every one-group pipeline whose schedule lives on ONE stream (the deferred products and the split
+    // build fork to side streams with CU-reserving launches and stay eager), up to npad = 4096.
     if (groups == 1 && defer_node == 0 && !use_rl && !use_dag && c->graph_max_npad > 0 && npad <= c->graph_max_npad && !kmode()) {
       int rc = graph_section(cnt);
       if (rc) return rc;
@@ -1741,12 +1777,15 @@ struct Pipe {
       if (noise_N > 0 && b.vec_noise)
         HIPCHK(c, c->pin.gather(&ng[(size_t)s0 * noise_N], c->ng.p, (size_t)cnt * noise_N * 8, st));
     }
+#ifdef GPC_EXPERIMENTS
     int dag_words[2] = {0, 0};  // [abort, leaf servers started] of the graph, when one ran
     if (c->dag_used)
       HIPCHK(c, c->pin.gather(dag_words, reinterpret_cast<char*>(c->dag_ctl.p) + offsetof(DagCtl, abort), 8, st));
+#endif
     HIPCHK(c, c->pin.flush_down(st));
     HIPCHK(c, hipStreamSynchronize(st));
     c->pin.finish();
+#ifdef GPC_EXPERIMENTS
     if (c->dag_used && dag_trace_n > 0 && getenv("GPC_DAG_TRACE")) {  // every (sample, task)'s times, one line each, to the named file
       std::vector<long long> tr((size_t)dag_trace_n * 6);
       (void)hipMemcpy(tr.data(), c->dbg2.p, tr.size() * sizeof(long long), hipMemcpyDeviceToHost);
@@ -1795,11 +1834,12 @@ struct Pipe {
       for (int g = 0; g <= gpc_ctx::MAXG; ++g) lauum_n[g] = 0;
       return DAG_RETRY;
     }
+#endif
     memcpy(&logdet[s0], hscal.data(), (size_t)cnt * 8);
     memcpy(&quad[s0], hscal.data() + cnt, (size_t)cnt * 8);
     if (getenv("GPC_SCALAR_LOG"))
       for (int i = 0; i < cnt; ++i)
-        fprintf(stderr, "[gpcore] sample %d dag=%d logdet %.17g quad %.17g\n", s0 + i, (int)c->dag_used, logdet[s0 + i], quad[s0 + i]);
+        fprintf(stderr, "[gpcore] sample %d logdet %.17g quad %.17g\n", s0 + i, logdet[s0 + i], quad[s0 + i]);
     memcpy(hinfo.data(), hscal.data() + 2 * (size_t)cnt, (size_t)cnt * sizeof(int));
     hc.lap("d2h+sync");
     for (int i = 0; i < cnt; ++i) b.info[s0 + i] = hinfo[i];
@@ -2064,8 +2104,8 @@ int check_batch_args(gpc_ctx* c, int kernel_id, int degree, int dtype, int S) {
   if (dtype != GPC_F64 && dtype != GPC_F32) FAIL(c, "dtype must be GPC_F64 or GPC_F32");
   if (S <= 0) FAIL(c, "S must be positive");
   if (c->N > gpc_max_n(dtype))
-    FAIL(c, "N is beyond the supported size for this dtype (an operand panel must stay below 2 GiB: "
-            "N <= 16384 in fp64, N <= 23168 in fp32)");
+    FAIL(c, "N is beyond what this device's memory holds for this dtype (three padded N x N slabs of one sample must fit "
+            "in 80 % of it: gpc_max_n)");
   return 0;
 }
 
@@ -2207,8 +2247,6 @@ int rhs_products(gpc_post* po, int mode, const double* xa, const double* xb, int
   const int S = po->S, N = po->N, D = po->D, npad = po->npad;
   const int mpad = pad_tile(M);
   hipStream_t st = c->st;
-  if ((long long)npad * mpad * (long long)sizeof(T) + 4096 >= (1ll << 31))
-    FAIL(c, "too many query points for one call at this N (N_pad * M_pad * sizeof(T) must stay below 2 GiB)");
   const long long sM = (long long)npad * npad;
   const long long sKs = (long long)npad * mpad;
   const long long sKss = (long long)mpad * mpad;
@@ -2513,7 +2551,7 @@ int debug_gemm_impl(gpc_ctx* c, int M, int N, int K, int akm, int bkm, double al
   g.khi = khi;
   g.lower_only = lower & 1;
   g.tiles_n = N / TILE;
-  HIPCHK(c, launch_gemm<T>(c->st, g, akm != 0, bkm != 0, 1, (lower & 0x100) ? 64 : ((lower & 0x200) ? 128 : ((lower & 0x400) ? 12864 : 0))));
+  HIPCHK(c, launch_gemm<T>(c->st, g, akm != 0, bkm != 0, 1, (lower & 0x100) ? 64 : ((lower & 0x200) ? 128 : ((lower & 0x400) ? 12864 : 0))));  // (12864: experiments build)
   return download_as<T>(c, c->dbg3.as<T>(), C, (size_t)M * N);
 }
 
@@ -2831,11 +2869,13 @@ int gpc_create(int device, gpc_ctx** out) {
   if (const char* e = getenv("GPC_LEAF")) gpc::g_leaf_version = atoi(e) == 3 ? 3 : 5;
   if (const char* e = getenv("GPC_SMALL_PATH")) c->small_path = atoi(e) != 0;
   if (const char* e = getenv("GPC_GRAPH_MAX_NPAD")) c->graph_max_npad = atoi(e);
+#ifdef GPC_EXPERIMENTS
   if (const char* e = getenv("GPC_RL_PANEL")) c->rl_panel = atoi(e) <= 0 ? 0 : std::max(TILE, (atoi(e) / TILE) * TILE);
+  if (const char* e = getenv("GPC_RECT_MIN")) gpc::g_rect_min_blocks = atoi(e);
+#endif
   if (const char* e = getenv("GPC_NLL_BLOCK")) c->nll_block = atoi(e) < 0 ? -1 : (atoi(e) == 0 ? 0 : std::max(TILE, (atoi(e) / TILE) * TILE));
   if (const char* e = getenv("GPC_GROUPS")) c->groups = std::max(1, std::min((int)gpc_ctx::MAXG, atoi(e)));
   if (const char* e = getenv("GPC_SMALL_BLOCKS")) gpc::g_small_launch_blocks = atoi(e);
-  if (const char* e = getenv("GPC_RECT_MIN")) gpc::g_rect_min_blocks = atoi(e);
   if (const char* e = getenv("GPC_DUAL")) gpc::g_dual_launch = atoi(e) != 0;
   if (const char* e = getenv("GPC_GEMM_FLAGS")) gpc::g_gemm_flags = atoi(e);
   if (const char* e = getenv("GPC_XCD_AFFINE")) gpc::g_gemm_flags = atoi(e) ? (gpc::g_gemm_flags | 8) : (gpc::g_gemm_flags & ~8);
@@ -2885,13 +2925,20 @@ const char* gpc_device_info(gpc_ctx* c) { return c ? c->devinfo.c_str() : ""; }
 int gpc_cov_count(int kernel_id, int D) { return cov_count_of(kernel_id, D); }
 
 int gpc_max_n(int dtype) {
-  // The GEMM stages operands through raw buffer descriptors based at the tile origin with 32-bit
-  // byte offsets (gemm.h): a k-major panel spans (npad - 1) * npad elements, which must stay
-  // below 2^31 bytes.
+  // A memory-budget answer (round 6; rounds 1-5: 16384 / 23168, the reach of one 32-bit byte offset over a k-major
+  // operand panel, which gemm.h no longer has): the largest N, a multiple of 128, whose three padded slabs A, W and
+  // scratch (plan.h) of ONE sample fit in 80 % of the current device's memory -- what nll_impl / post_impl budget a chunk
+  // with.  Without a device: the MI355X's 288 GB.
   const long long w = dtype == GPC_F32 ? 4 : 8;
-  long long n = TILE;
-  while ((n + TILE - 1) * (n + TILE) * w + 4096 < (1ll << 31)) n += TILE;
-  return (int)n;
+  size_t fr = 0, total = 0;
+  if (hipMemGetInfo(&fr, &total) != hipSuccess || total == 0) {
+    (void)hipGetLastError();
+    total = (size_t)288 << 30;
+  }
+  const double budget = 0.8 * (double)total / (3.0 * (double)w);
+  long long n = (long long)std::floor(std::sqrt(budget) / TILE) * TILE;
+  // (tile and element counts are 32-bit in the kernels' index arithmetic up to (npad / 64)^2 tiles: far beyond any memory)
+  return (int)std::max<long long>(TILE, std::min<long long>(n, 1 << 20));
 }
 
 int gpc_set_data(gpc_ctx* c, const double* X, const double* y, int N, int D) {
@@ -3305,6 +3352,43 @@ int gpc_last_timing(gpc_ctx* c, double* ms_total, double* ms_factor) {
   return 0;
 }
 
+namespace {
+#ifdef GPC_EXPERIMENTS
+// options of the schedules that exist in the experiments build only (see the include of dag.h)
+int* experiment_option(gpc_ctx* c, const std::string& n) {
+  if (n == "rect_min") return &gpc::g_rect_min_blocks;  // launches of at least this many 128-tiles (x samples) below the 128-tile threshold run as 128 x 64 tiles (0: off)
+  if (n == "rect_mode") return &gpc::g_rect_mode;       // what "rect_min" selects: 0 = 128 x 64 tiles of four waves, 1 = 128 x 128 tiles of eight waves
+  if (n == "indep") return &c->indep;                   // independent pipelines for batches of 2 .. indep_max samples at npad >= 2048 (0: lock-step)
+  if (n == "indep_max") return &c->indep_max;
+  if (n == "indep_min_tiles") return &c->indep_min_tiles;
+  if (n == "rl_ahead_max") return &c->rl_ahead_max;     // look-ahead of the right-looking plan only up to this batch work S (npad/4096)^3
+  if (n == "rl_panel") return &c->rl_panel;             // NLL-only: right-looking panels of this many rows with look-ahead (0: off)
+  if (n == "dag") return &c->dag;
+  if (n == "dag_small_tiles") return &c->dag_small_tiles;
+  if (n == "dag_lauum") return &c->dag_lauum;
+  if (n == "dag_leaf_blocks") return &c->dag_leaf_blocks;
+  if (n == "dag_aborts") return &c->dag_aborts;         // (tests: forget earlier aborts -- three of them switch the graph off for the context)
+  if (n == "dag_runs") return &c->dag_runs;
+  if (n == "dag_urgent_cus") return &c->dag_urgent_cus;
+  if (n == "dag_gate") return &c->dag_gate;
+  if (n == "dag_gate_pct") return &c->dag_gate_pct;
+  if (n == "dag_crit_pct") return &c->dag_crit_pct;
+  if (n == "dag_timeout_ms") return &c->dag_timeout_ms;
+  return nullptr;
+}
+int clamp_experiment_option(const std::string& n, int value) {
+  if (n == "indep_max") return std::max(2, std::min((int)gpc_ctx::MAXG, value));
+  if (n == "indep_min_tiles") return std::max(1, value);
+  if (n == "rect_mode") return value != 0;
+  if (n == "rl_panel") return value <= 0 ? 0 : std::max(TILE, (value / TILE) * TILE);
+  if (n == "dag_urgent_cus") return std::max(0, std::min(15, value));
+  if (n == "dag_gate_pct" || n == "dag_crit_pct") return std::max(0, std::min(100, value));
+  if (n == "dag_timeout_ms") return std::max(1, value);  // (a wait of no length would abort every graph at once: ADVICE r5)
+  return value;
+}
+#endif
+}  // namespace
+
 int gpc_set_option(gpc_ctx* c, const char* name, int value) {
   if (!c || !name) return -2;
   const std::string n(name);
@@ -3312,16 +3396,6 @@ int gpc_set_option(gpc_ctx* c, const char* name, int value) {
     c->groups = std::max(1, std::min((int)gpc_ctx::MAXG, value));
   else if (n == "small_blocks")
     gpc::g_small_launch_blocks = value;
-  else if (n == "rect_min")  // launches of at least this many 128-tiles (x samples) below the 128-tile threshold run as 128 x 64 tiles (0: off)
-    gpc::g_rect_min_blocks = value;
-  else if (n == "indep")  // independent pipelines for batches of 2 .. indep_max samples at npad >= 2048 (0: lock-step)
-    c->indep = value;
-  else if (n == "indep_max")
-    c->indep_max = std::max(2, std::min((int)gpc_ctx::MAXG, value));
-  else if (n == "indep_min_tiles")
-    c->indep_min_tiles = std::max(1, value);
-  else if (n == "rect_mode")  // what "rect_min" selects: 0 = 128 x 64 tiles of four waves, 1 = 128 x 128 tiles of eight waves
-    gpc::g_rect_mode = value != 0;
   else if (n == "dual_launch")  // syrk + inverse product of a node in one launch (default 1)
     gpc::g_dual_launch = value != 0;
   else if (n == "leaf")  // 5: pipelined leaf (default), 3: barrier-per-phase leaf (A/B and bit-identity tests)
@@ -3337,42 +3411,24 @@ int gpc_set_option(gpc_ctx* c, const char* name, int value) {
     c->nll_block = value < 0 ? -1 : (value == 0 ? 0 : std::max(TILE, (value / TILE) * TILE));
   else if (n == "solves_beside_lauum")  // 0: the triangular mat-vecs after the W^T W launch (round-2 order)
     c->solves_beside_lauum = value != 0;
-  else if (n == "rl_ahead_max")  // look-ahead of the right-looking plan only up to this batch work S (npad/4096)^3
-    c->rl_ahead_max = value;
-  else if (n == "rl_panel")  // NLL-only: right-looking panels of this many rows with look-ahead (0: off)
-    c->rl_panel = value <= 0 ? 0 : std::max(TILE, (value / TILE) * TILE);
   else if (n == "stable")  // every factorization in stable mode (refined panel solves, plan.h), not only the jitter retries
     c->stable = value != 0;
   else if (n == "small_path")  // 0: problems of one leaf take the general pipeline too (A/B and cross-checks)
     c->small_path = value != 0;
-  else if (n == "dag")
-    c->dag = value;
-  else if (n == "dag_small_tiles") {
-    c->dag_small_tiles = value;
-  } else if (n == "dag_lauum")
-    c->dag_lauum = value;
-  else if (n == "dag_leaf_blocks")
-    c->dag_leaf_blocks = value;
-  else if (n == "dag_aborts")  // (tests: forget earlier aborts -- three of them switch the graph off for the context)
-    c->dag_aborts = value;
-  else if (n == "dag_urgent_cus")
-    c->dag_urgent_cus = std::max(0, std::min(15, value));
-  else if (n == "dag_gate")
-    c->dag_gate = value;
-  else if (n == "dag_gate_pct")
-    c->dag_gate_pct = std::max(0, std::min(100, value));
-  else if (n == "dag_crit_pct")
-    c->dag_crit_pct = std::max(0, std::min(100, value));
-  else if (n == "dag_timeout_ms")
-    c->dag_timeout_ms = value;
   else if (n == "check_queues")  // debug: verify the tile queues of persistent launches after every pipeline
     c->check_queues = value != 0;
   else if (n == "start_mult_log10")  // test hook: first jitter multiplier 10^value
     c->start_mult = std::pow(10.0, std::max(0, std::min(9, value)));
   else if (n == "append_fail_mask")  // test hook: samples whose rank-one append is declared unstable
     c->append_fail_mask = (unsigned)value;
-  else
-    FAIL(c, "gpc_set_option: unknown option");
+  else {
+#ifdef GPC_EXPERIMENTS
+    if (int* slot = experiment_option(c, n))
+      *slot = clamp_experiment_option(n, value);
+    else
+#endif
+      FAIL(c, "gpc_set_option: unknown option");
+  }
   ++g_alloc_epoch;  // cached launch graphs captured the old launch shapes
   return 0;
 }
@@ -3388,28 +3444,23 @@ int gpc_get_option(gpc_ctx* c, const char* name, int* value) {
   else if (n == "defer_reserve") *value = c->defer_reserve;
   else if (n == "nll_block") *value = c->nll_block;
   else if (n == "solves_beside_lauum") *value = c->solves_beside_lauum;
-  else if (n == "rl_ahead_max") *value = c->rl_ahead_max;
-  else if (n == "rl_panel") *value = c->rl_panel;
   else if (n == "stable") *value = c->stable;
   else if (n == "small_path") *value = c->small_path;
   else if (n == "check_queues") *value = c->check_queues;
-  else if (n == "rect_min") *value = gpc::g_rect_min_blocks;
-  else if (n == "rect_mode") *value = gpc::g_rect_mode;
-  else if (n == "indep") *value = c->indep;
-  else if (n == "indep_max") *value = c->indep_max;
-  else if (n == "indep_min_tiles") *value = c->indep_min_tiles;
-  else if (n == "dag") *value = c->dag;
-  else if (n == "dag_small_tiles") *value = c->dag_small_tiles;
-  else if (n == "dag_lauum") *value = c->dag_lauum;
-  else if (n == "dag_leaf_blocks") *value = c->dag_leaf_blocks;
-  else if (n == "dag_gate") *value = c->dag_gate;
-  else if (n == "dag_urgent_cus") *value = c->dag_urgent_cus;
-  else if (n == "dag_gate_pct") *value = c->dag_gate_pct;
-  else if (n == "dag_crit_pct") *value = c->dag_crit_pct;
-  else if (n == "dag_timeout_ms") *value = c->dag_timeout_ms;
-  else if (n == "dag_runs") *value = c->dag_runs;
-  else if (n == "dag_aborts") *value = c->dag_aborts;
-  else FAIL(c, "gpc_get_option: unknown option");
+  else if (n == "experiments") {  // 1: this library is the experiments build (tests/ and tools/ ask before they use its options)
+#ifdef GPC_EXPERIMENTS
+    *value = 1;
+#else
+    *value = 0;
+#endif
+  } else {
+#ifdef GPC_EXPERIMENTS
+    if (int* slot = experiment_option(c, n))
+      *value = *slot;
+    else
+#endif
+      FAIL(c, "gpc_get_option: unknown option");
+  }
   return 0;
 }
 
@@ -3511,6 +3562,9 @@ int gpc_debug_gemm(gpc_ctx* c, int dtype, int M, int N, int K, int a_kmajor, int
   if (!c) return -2;
   if (M % TILE || N % TILE || K % TILE || M <= 0 || N <= 0 || K <= 0) FAIL(c, "gpc_debug_gemm: sizes must be multiples of 128");
   if ((lower_only & 1) && M != N) FAIL(c, "gpc_debug_gemm: lower_only needs M == N");
+#ifndef GPC_EXPERIMENTS
+  if (lower_only & 0x400) FAIL(c, "gpc_debug_gemm: the rectangular tile exists in the experiments build only");
+#endif
   HIPCHK(c, hipSetDevice(c->device));
   return dtype == GPC_F64
              ? debug_gemm_impl<double>(c, M, N, K, a_kmajor, b_kmajor, alpha, beta, klo, khi, lower_only, A, B, C)
@@ -3551,6 +3605,7 @@ int gpc_debug_workspace_hash(gpc_ctx* c, int dtype, int which, int sample, unsig
   return 0;
 }
 
+#ifdef GPC_EXPERIMENTS
 // Host-only (no device call): the tile-task graph dag.h derives for a factorization of an npad x npad matrix.
 int gpc_debug_dag(int npad, int plan, int nll_blk, int small_tiles, int* counts, int* tasks_out, double* alpha_out,
                   int* succ_out, int cap_tasks, int cap_edges) {
@@ -3612,5 +3667,7 @@ int gpc_debug_dag(int npad, int plan, int nll_blk, int small_tiles, int* counts,
   memcpy(succ_out, P.succ.data(), P.succ.size() * sizeof(int));
   return 0;
 }
+
+#endif  // GPC_EXPERIMENTS
 
 }  // extern "C"

@@ -23,6 +23,7 @@
 
 namespace gpc {
 
+#ifdef GPC_EXPERIMENTS
 // Recording mode (dag.h): instead of launching, the plan appends every product and every leaf to a list, in launch
 // order -- the tile-level dataflow schedule is derived from exactly the launches the stream-ordered schedule would
 // have issued, so both run the same tile arithmetic.
@@ -36,10 +37,15 @@ struct PlanRecorder {
   std::vector<Op> ops;
   bool unsupported = false;  // the plan asked for something the dataflow kernel does not do (L21 copies, stable leaves)
 };
+#endif
 
 template <typename T>
 struct Factor {
-  PlanRecorder* rec = nullptr;
+#ifdef GPC_EXPERIMENTS
+  PlanRecorder* rec = nullptr;  // experiments build: record the plan instead of issuing it (dag.h)
+#else
+  static constexpr void* rec = nullptr;  // (the product library issues every launch; `if (rec)` folds away)
+#endif
   hipStream_t st;
   int batch;
   int npad;
@@ -69,8 +75,14 @@ struct Factor {
     int ntiles, batch;
   };
   std::vector<QueueCheck>* qlog = nullptr;
-  bool reserve_all = false;  // see gemm(): all chip-filling launches of this pipeline are CU-reserving
+#ifdef GPC_EXPERIMENTS
+  bool reserve_all = false;  // see gemm(): all chip-filling launches of this pipeline are CU-reserving (independent pipelines)
   int reserve_min = 64;
+  int reserved_small_bt = 128;  // tile of a reserved launch below the 128-tile threshold (64: independent pipelines)
+#else
+  static constexpr bool reserve_all = false;
+  static constexpr int reserve_min = 64, reserved_small_bt = 128;
+#endif
   bool dual_launch = g_dual_launch;  // syrk + inverse product of a node in one launch where both are small
   // Stable mode (the jitter retries, gpcore.hip: retry_failed): the trsm-as-a-product T21 = A21 W11^T has an error of
   // cond(L11) eps instead of eps, which on a numerically singular matrix makes the factorization fail where a
@@ -140,10 +152,12 @@ struct Factor {
     g.tiles_n = N / TILE;
     flops += gemm_flops(g, batch);
     ++launches;
+#ifdef GPC_EXPERIMENTS
     if (rec) {
       rec->ops.push_back({0, g, akm, bkm, 0});
       return;
     }
+#endif
     int* slot = nullptr;  // CTR_STRIDE counters per persistent launch
     // only launches that will run in the persistent form take a slot: a factorization of npad = 8192 or
     // 16384 has 250-500 launches, and the big ones (which need the slots) come last in the order
@@ -158,7 +172,7 @@ struct Factor {
       ctr_used += CTR_STRIDE;
       if (qlog) qlog->push_back({slot, (int)(lower ? tm * (tm + 1) / 2 : tm * tn), batch});
     }
-    hipError_t e = launch_gemm<T>(on ? on : st, g, akm, bkm, batch, 0, slot, rsv);
+    hipError_t e = launch_gemm<T>(on ? on : st, g, akm, bkm, batch, 0, slot, rsv, reserved_small_bt);
     if (e != hipSuccess && err == hipSuccess) err = e;
   }
 
@@ -169,6 +183,7 @@ struct Factor {
   void potrf_inv(int off, int n, bool need_inv, bool keep_L) {
     keep_L = keep_L || stable;
     if (n == TILE) {
+#ifdef GPC_EXPERIMENTS
       if (rec) {
         if (stable) rec->unsupported = true;
         rec->ops.push_back({1, GemmArgs{}, false, false, off});
@@ -176,6 +191,7 @@ struct Factor {
         ++launches;
         return;
       }
+#endif
       need_rows(off + TILE);
       launch_leaf<T>(st, batch, blk(A, off, off), sA, npad, blk(W, off, off), sW, npad, off, logdet, info,
                      std::max(0, std::min(TILE, nvalid - off)), stable);
@@ -249,7 +265,9 @@ struct Factor {
     }
     // L21 back into A: only where L must survive as the Cholesky factor (posteriors).  The blocked forward solve
     // of an NLL-only evaluation reads L21 where it was computed, in the scratch (forward_solve below).
+#ifdef GPC_EXPERIMENTS
     if (keep_L && rec) rec->unsupported = true;
+#endif
     if (keep_L && !rec) {
       dim3 grid((n1 + 64 * MM<T>::VEC - 1) / (64 * MM<T>::VEC), n2 / 32, batch), block(64, 4);
       hipLaunchKernelGGL((rect_copy_kernel<T>), grid, block, 0, st, (const T*)blk(Tm, o2, o1), sT, npad,
@@ -324,6 +342,7 @@ struct Factor {
     forward_solve_nll(off + n1, n2, r, z);
   }
 
+#ifdef GPC_EXPERIMENTS
   // ---- right-looking panels with one panel of look-ahead (round 3) ------------------------------------------------
   // The recursion above exposes every latency-bound stretch of a child (its leaves, its deep-level products) on the
   // critical path.  Here the matrix is factored in panels of `rl_panel` rows, right-looking:
@@ -389,6 +408,8 @@ struct Factor {
       }
     }
   }
+
+#endif  // GPC_EXPERIMENTS
 
   // z = L^-1 r after potrf_inv(.., need_inv): blocks that own their full inverse multiply
   // by W, the others split like the factorization and eliminate with L21 (kept in A for

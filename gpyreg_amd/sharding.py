@@ -155,16 +155,21 @@ class _Gather:
                     torch.cuda.current_stream().synchronize()
             full = vout.reshape(self.world, self.maxrows, -1)
             if self.raw:
-                return full.copy()
-            rows = []
-            for r in range(self.world):
-                lo, hi = shard_bounds(self.S, r, self.world)
-                rows.append(full[r, : hi - lo])
-            return np.concatenate(rows, axis=0)  # (a copy: the buffers go back to the pool)
-        finally:
-            # the collective has completed or failed: either way nothing is in flight on these buffers any more
-            _give_back(self.key, self.bufs)
+                res = full.copy()
+            else:
+                rows = []
+                for r in range(self.world):
+                    lo, hi = shard_bounds(self.S, r, self.world)
+                    rows.append(full[r, : hi - lo])
+                res = np.concatenate(rows, axis=0)  # (a copy: the buffers go back to the pool)
+        except BaseException:
+            # a wait that raised (time-out, asynchronous RCCL error) says nothing about the collective having stopped
+            # writing out / hout: the buffers are dropped, as __init__ drops them, never handed to the next gather
             self.bufs = None
+            raise
+        _give_back(self.key, self.bufs)  # completed: nothing is in flight on these buffers any more
+        self.bufs = None
+        return res
 
 
 def _all_gather_rows(local: np.ndarray, S: int, group=None) -> np.ndarray:

@@ -47,9 +47,12 @@ int gpc_set_data(gpc_ctx* ctx, const double* X, const double* y, int N, int D);
 /* number of covariance hyperparameters (covariance_functions.py:59-73, :291-292;
  * isotropic_covariance_functions.py:14-28) */
 int gpc_cov_count(int kernel_id, int D);
-/* Largest N the dense stages accept for a dtype (16384 in fp64, 23168 in fp32): an operand
- * panel is addressed through one buffer descriptor with 32-bit byte offsets and must stay
- * below 2 GiB.  The batch entry points return -2 above it (no device needed to ask).       */
+/* Largest N the dense stages accept for a dtype: a MEMORY-BUDGET answer (round 6) -- the largest multiple of 128 whose
+ * three padded N x N slabs of one sample (matrix / factor, inverse factor, scratch) fit in 80 % of the current device's
+ * memory (fp64 on a 288 GB MI355X: 97 920; fp32: 138 496).  The reference factorizes whatever fits host memory
+ * (gaussian_process.py:2415-2417, :2477-2484); so does this library with device memory.  (Rounds 1-5 answered 16384 /
+ * 23168: one 32-bit byte offset spanned a k-major operand panel.  The GEMM now advances a 64-bit base per k-slab.)
+ * The batch entry points return -2 above it.  Without a visible device the answer assumes 288 GB.                       */
 int gpc_max_n(int dtype);
 
 /* ---- covariance.compute() (covariance_functions.py:135-186, :221-285, :301-367;
@@ -201,7 +204,7 @@ int gpc_last_lauum_timing(gpc_ctx* ctx, double* ms, double* flops);
  * "defer_reserve" = CUs per XCD that launch keeps empty (2 | 4 | 8 | 12).  Test hooks:
  * "start_mult_log10" = k starts the jitter escalation of every factorization at 10^k instead of 1
  * (gaussian_process.py:2402), "append_fail_mask" = bit s declares the rank-one append of sample s
- * unstable (:789-798).                                                                            */
+ * unstable (:789-798).  "experiments" (get only): 1 when the loaded library is the experiments build.   */
 int gpc_set_option(gpc_ctx* ctx, const char* name, int value);
 /* Current value of a tuning switch (so that a caller that changes one for a measurement can put it back). */
 int gpc_get_option(gpc_ctx* ctx, const char* name, int* value);
@@ -216,8 +219,8 @@ int gpc_mfma_peak(gpc_ctx* ctx, int dtype, double* tflops, double* cycles_per_mf
  * C[M x N] = beta*C + alpha*op(A)op(B) with the library's tiled MFMA GEMM.
  * a_kmajor: A stored K x M (else M x K); b_kmajor: B stored K x N (else N x K).
  * M, N, K multiples of 128.  klo/khi/lower_only: per-tile k-range modes (see
- * gpyreg_amd/csrc/gemm.h); lower_only bit 0 = lower tiles only, 0x400 forces the 128 x 64 tile, 0x100 / 0x200 force
- * the 64- / 128-tile kernel variant.                                               */
+ * gpyreg_amd/csrc/gemm.h); lower_only bit 0 = lower tiles only, 0x100 / 0x200 force the 64- / 128-tile kernel variant
+ * (0x400, experiments build only: the 128 x 64 tile).                              */
 int gpc_debug_gemm(gpc_ctx* ctx, int dtype, int M, int N, int K, int a_kmajor,
                    int b_kmajor, double alpha, int beta, int klo, int khi,
                    int lower_only, const double* A, const double* B, double* C);
@@ -231,6 +234,11 @@ int gpc_debug_factor(gpc_ctx* ctx, int dtype, int n, const double* A, double* L,
 /* Debug: wrapping-sum hash of every 128 x 128 tile of one workspace matrix as the LAST call left it (which: 0 = A, 1 = W,
  * 2 = T; sample: position in the last chunk); out[(npad/128)^2].  Finds the tile where two schedules differ.          */
 int gpc_debug_workspace_hash(gpc_ctx* ctx, int dtype, int which, int sample, unsigned long long* out);
+/* ---- experiments build only (hipcc -DGPC_EXPERIMENTS -> lib/libgpcore_exp.so; NOT part of the product library) --------
+ * Schedules that were built, measured and rejected (tile-level dataflow graph, independent pipelines,
+ * rectangular / eight-wave tiles, right-looking panels) and their gpc_set_option names live there;
+ * gpc_get_option(ctx, "experiments") says which build is loaded.                                                        */
+#ifdef GPC_EXPERIMENTS
 /* The tile-task graph of the dataflow schedule (gpyreg_amd/csrc/dag.h) for an npad x npad factorization --
  * HOST ONLY, no device needed: tests/test_dag_model.py executes it with NumPy tiles in random valid orders.
  * plan: 0 = NLL only (blocked solves above nll_blk rows when nll_blk > 0), 1 = factor + inverse + W^T W,
@@ -240,6 +248,8 @@ int gpc_debug_workspace_hash(gpc_ctx* ctx, int dtype, int which, int sample, uns
  * successor lists.  Returns 0, -1 (plan not supported), -2 (bad arguments), -3 (buffers too small).               */
 int gpc_debug_dag(int npad, int plan, int nll_blk, int small_tiles, int* counts, int* tasks_out,
                   double* alpha_out, int* succ_out, int cap_tasks, int cap_edges);
+
+#endif /* GPC_EXPERIMENTS */
 
 #ifdef __cplusplus
 }

@@ -16,6 +16,27 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line(
+        "markers", "experiments: needs the experiments build of the library (python -m gpyreg_amd.build --experiments, "
+                   "then GPYREG_AMD_LIB=gpyreg_amd/lib/libgpcore_exp.so); skipped with the product library")
+
+
+def pytest_collection_modifyitems(config, items):
+    """Tests of the schedules that live in the experiments build only (dataflow graph, independent pipelines,
+    rectangular tiles, right-looking panels) opt in: they run when GPYREG_AMD_LIB selects that build."""
+    marked = [it for it in items if it.get_closest_marker("experiments")]
+    if not marked:
+        return
+    try:
+        from gpyreg_amd import _lib
+
+        on = _lib.is_experiments_build()
+    except Exception:  # noqa: BLE001 - no library at all: the ABI tests report that
+        on = False
+    if not on:
+        skip = pytest.mark.skip(reason="experiments build only (GPYREG_AMD_LIB=gpyreg_amd/lib/libgpcore_exp.so)")
+        for it in marked:
+            it.add_marker(skip)
 
 
 def _load(name):

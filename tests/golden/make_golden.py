@@ -23,6 +23,9 @@ Files written next to this script:
                    file: ORACLE-DERIVED (oracle.core_streamed, one gradient plane at a time, ~20 GB, ~10 min) because
                    the reference needs 47 GB here; the script asserts that the streamed oracle's nlZ is the
                    reference's stored cfg4 nlZ bit for bit before it writes the gradient
+  big20k_case.npz  N = 20480 (beyond the device library's former 16384 ceiling), D = 5, SE: the reference's nlZ and the
+                   streamed oracle's gradient (oracle-derived, labelled; written only if its nlZ is the reference's bit for
+                   bit); target `big20k`
   rank1_cases.npz  GP.update with ONE new point (the reference's rank-one path,
                    gaussian_process.py:750-844), high- and low-noise parametrisation
   api_sweep_reference.txt  (not written by this script) the output of tools/api_sweep.py run against the reference:
@@ -553,6 +556,36 @@ def cfg4_gradient():
     np.savez_compressed(path, **out)
 
 
+def big20k_case():
+    """Beyond the former N <= 16384 ceiling of the device library: N = 20480, D = 5, squared exponential, one sample
+    (the inputs are bench.py's `--config 6` draw at that N, regenerated from the seed).  The reference computes nlZ
+    (no gradient: its (N, N, 6) tensor would need 20 GB on top of K, L and the inverse); the gradient is ORACLE-DERIVED
+    (oracle.core_streamed, one plane at a time), written only after its nlZ has been found equal to the reference's
+    bit for bit, and labelled as such."""
+    import time
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import gp_oracle as orc
+
+    N, D = 20480, 5
+    X, y, hyp = _bench_problem(6, N, D, "se", 2)
+    gp = gpr.GP(D=D, covariance=KERNELS["se"](), mean=MEANS["const"](), noise=make_noise((1, 0, 0)))
+    gp.X, gp.y = X, y
+    t0 = time.time()
+    ref_nlZ = gp._GP__compute_nlZ(hyp[0], False, False)
+    print(f"big20k reference: nlZ={ref_nlZ!r} (no gradient, {time.time() - t0:.0f} s)", flush=True)
+    model = dict(kernel="se", degree=0, mean="const", noise=(1, 0, 0))
+    t0 = time.time()
+    nlZ, dnlZ = orc.core_streamed(model, hyp[0], X, y, None)
+    print(f"big20k streamed oracle: nlZ={nlZ!r} ({time.time() - t0:.0f} s)", flush=True)
+    print("dnlZ =", np.array2string(dnlZ, precision=17))
+    assert nlZ == ref_nlZ, "the streamed oracle's nlZ is not the reference's"
+    out = dict(N=np.array(N), D=np.array(D), hyp=hyp[:1], nlZ=np.array([ref_nlZ]), dnlZ=dnlZ[None, :],
+               dnlZ_source=np.array("oracle.core_streamed (oracle-derived; its nlZ equals the reference's bit for bit)"),
+               Xsum=np.array([X.sum(), y.sum()]))
+    np.savez_compressed(os.path.join(HERE, "big20k_case.npz"), **out)
+
+
 def rank1_cases():
     """GP.update(X_new=1 point, y_new) through the reference's rank-one path (:750-844):
     three consecutive appends; posterior fields after the last one, predictions after each."""
@@ -683,6 +716,8 @@ if __name__ == "__main__":
         fullsize45_cases()
     if "cfg4grad" in which:  # ~10 minutes, ~20 GB; oracle-derived (see cfg4_gradient)
         cfg4_gradient()
+    if "big20k" in which:  # ~15 minutes, ~25 GB; gradient oracle-derived (see big20k_case)
+        big20k_case()
     if "rank1" in which:
         rank1_cases()
     if "cov" in which:

@@ -23,11 +23,36 @@ def test_library_builds_and_exports_every_declared_symbol():
     lib = _lib.load()
     header = open(os.path.join(ROOT, "include", "gpcore.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
-    declared = set(re.findall(r"\b(gpc_[A-Za-z0-9_]+)\s*\(", header))
+    # declarations under GPC_EXPERIMENTS belong to the experiments build (lib/libgpcore_exp.so), not to the product
+    experiments = "".join(re.findall(r"#ifdef GPC_EXPERIMENTS(.*?)#endif", header, flags=re.S))
+    product = re.sub(r"#ifdef GPC_EXPERIMENTS.*?#endif", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(gpc_[A-Za-z0-9_]+)\s*\(", product))
+    declared_exp = set(re.findall(r"\b(gpc_[A-Za-z0-9_]+)\s*\(", experiments))
     assert declared, "no declarations parsed"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert declared_exp == set(_lib.EXPERIMENT_SIGNATURES), declared_exp ^ set(_lib.EXPERIMENT_SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
+    if os.path.basename(_lib.LIB_PATH) == "libgpcore.so":  # the product exports none of the experiment entries
+        for name in declared_exp:
+            assert not hasattr(lib, name), name
+
+
+def test_the_product_library_holds_the_shipped_schedule_only():
+    """The schedules that were measured and rejected (dataflow graph, independent pipelines, rectangular tiles,
+    right-looking panels) are compiled under GPC_EXPERIMENTS only: the product library has neither
+    their kernels nor their option names."""
+    import subprocess
+
+    from gpyreg_amd import _lib
+
+    if os.path.basename(_lib.LIB_PATH) != "libgpcore.so":
+        pytest.skip("an alternative library was selected through GPYREG_AMD_LIB")
+    syms = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    raw = open(_lib.LIB_PATH, "rb").read()
+    for needle in (b"dag_worker_kernel", b"dag_leaf_kernel", b"dag_small_tiles", b"indep_min_tiles", b"rect_min", b"rl_panel"):
+        assert needle not in raw, needle
+    assert "gpc_debug_dag" not in syms
 
 
 def test_cov_count_entry_point_without_gpu():
@@ -41,17 +66,18 @@ def test_cov_count_entry_point_without_gpu():
 
 
 def test_size_envelope_entry_point_without_gpu():
-    """gpc_max_n: an operand panel of the GEMM is addressed through one buffer descriptor with 32-bit
-    byte offsets, so (npad - 1) * npad * sizeof(T) must stay below 2^31; larger N is rejected by the
-    batch entry points (-2) instead of silently reading zeros."""
+    """gpc_max_n is a memory-budget answer (round 6): the largest multiple of 128 whose three padded slabs of one sample
+    fit in 80 % of the device's memory; without a device it assumes the MI355X's 288 GB.  (Rounds 1-5: 16384 / 23168,
+    the reach of a 32-bit byte offset over one operand panel.)"""
     from gpyreg_amd import _lib
 
     lib = _lib.load()
     for dtype, w in ((_lib.F64, 8), (_lib.F32, 4)):
         n = lib.gpc_max_n(dtype)
-        assert n % 128 == 0
-        assert (n - 1) * n * w + 4096 < 2**31 <= (n + 127) * (n + 128) * w + 4096
-    assert lib.gpc_max_n(_lib.F64) == 16384 and lib.gpc_max_n(_lib.F32) == 23168
+        assert n % 128 == 0 and n > 23168
+        if not _has_gpu():
+            total = 288 * 2**30
+            assert 3 * n * n * w <= 0.8 * total < 3 * (n + 128) * (n + 128) * w
 
 
 def test_assigning_data_attributes_marks_the_device_copy_stale():

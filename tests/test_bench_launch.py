@@ -224,3 +224,19 @@ def test_the_bench_line_carries_every_field_of_the_contract():
         assert k in cb, k
     assert cb["kind"] == "port" and cb["nlz_rel_err"] < 1e-8 and cb["grad_rel_err"] < 1e-8
     assert abs(line["value"] - 1.0 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]  # one sample per step
+    assert "10 evaluations" in cb["sample"] and "3 warm-up" in cb["sample"]  # BASELINE.md's protocol where it is cheap
+
+
+@pytest.mark.gpu
+def test_the_alone_figure_of_a_batch_that_runs_as_two_sample_groups():
+    """`roofline.alone` times the dominant launch in extra steps with ONE sample group; a batch beyond S (N_pad/4096)^3 = 64
+    runs its timed steps as TWO groups (two W^T W launches of S/2 samples each).  The alone figure must be priced with the
+    flops of the launch it timed (all S samples), not with the timed loop's per-group flops -- round 5 read 0.45 for a
+    launch that ran at 0.90.  N = 4096, 80 samples."""
+    r, line = _bench("--config", "3", "--samples", "80", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
+    assert r.returncode == 0, r.stderr[-3000:]
+    roof = line["roofline"]
+    alone = roof["alone"]
+    assert abs(alone["flops_per_launch"] - 2.0 * roof["flops_per_launch"]) < 1e-6 * alone["flops_per_launch"]
+    assert alone["frac"] >= roof["frac"] - 0.02, (alone["frac"], roof["frac"])
+    assert 0.5 < alone["frac"] < 1.0

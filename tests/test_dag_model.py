@@ -13,6 +13,8 @@ import pytest
 
 import dag_model
 
+pytestmark = pytest.mark.experiments  # gpc_debug_dag is exported by the experiments build only (conftest.py)
+
 
 def _spd(n, nvalid, seed):
     rng = np.random.default_rng(seed)

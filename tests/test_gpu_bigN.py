@@ -1,0 +1,106 @@
+"""Beyond N = 16384: the sizes the device library refused before round 6 (`gpc_max_n` was the reach of one 32-bit byte
+offset over a k-major operand panel of the GEMM; gemm.h now advances a 64-bit base per k-slab) and the reference accepts
+(it factorizes whatever fits host memory: gaussian_process.py:2415-2417, :2477-2484).
+
+* N = 20480, D = 5, squared exponential: nlZ against the REFERENCE's own value and the gradient against the streamed
+  oracle (oracle-derived and labelled so in tests/golden/big20k_case.npz, written only after its nlZ had been found equal
+  to the reference's bit for bit): fp64 1e-8, fp32 1e-3 -- north_star's tolerances.
+* N = 32768 (bench.py's `--config 6`), fp64, one and two samples: the size-independent properties -- a row of a batch
+  equals its single evaluation bit for bit, NLL-only equals the NLL of NLL + gradient to rounding, the gradient agrees
+  with a central difference along a random direction -- and a prediction against the posterior's own training targets.
+"""
+
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _problem(N, S):
+    import bench
+
+    cfg = dict(bench.CONFIGS[6])
+    try:
+        bench.CONFIGS[6] = dict(cfg, N=N)
+        return bench.synthetic_problem(6, S)
+    finally:
+        bench.CONFIGS[6] = cfg
+
+
+def test_the_size_envelope_is_the_memory_budget():
+    from gpyreg_amd import _lib
+
+    lib = _lib.load()
+    n64, n32 = lib.gpc_max_n(_lib.F64), lib.gpc_max_n(_lib.F32)
+    assert n64 >= 32768 and n32 > n64 and n64 % 128 == 0  # (a 288 GB MI355X: 97 920 / 138 496)
+
+
+@pytest.mark.parametrize("dtype,tol", [("f64", 1e-8), ("f32", 1e-3)])
+def test_n20480_against_the_reference_and_the_streamed_oracle(dtype, tol):
+    import bench
+
+    g = np.load(os.path.join(GOLDEN, "big20k_case.npz"), allow_pickle=False)
+    N = int(g["N"])
+    X, y, hyp = _problem(N, 2)
+    assert np.array_equal(np.array([X.sum(), y.sum()]), g["Xsum"]) and np.array_equal(hyp[:1], g["hyp"])
+    gp = bench.make_gp(6, dtype)
+    gp.update(X_new=X, y_new=y, hyp=hyp[:1], compute_posterior=False)
+    nlz, dnlz = gp.nll_batch(hyp[:1], compute_grad=True)
+    ref_n, ref_d = float(g["nlZ"][0]), g["dnlZ"][0]
+    assert abs(nlz[0] - ref_n) <= tol * abs(ref_n), (nlz[0], ref_n)
+    scale = np.maximum(np.abs(ref_d), np.abs(ref_d).max())
+    assert (np.abs(dnlz[0] - ref_d) <= tol * scale).all(), (dnlz[0], ref_d)
+    n0, _ = gp.nll_batch(hyp[:1], compute_grad=False)  # the N^3/3 plan (blocked solves) at this size
+    assert abs(n0[0] - ref_n) <= tol * abs(ref_n)
+
+
+def test_n32768_size_independent_properties():
+    import bench
+
+    N = bench.CONFIGS[6]["N"]
+    X, y, hyp = _problem(N, 2)
+    gp = bench.make_gp(6, "f64")
+    gp.update(X_new=X, y_new=y, hyp=hyp[:1], compute_posterior=False)
+    nlz, dnlz = gp.nll_batch(hyp, compute_grad=True)  # S = 2
+    assert np.isfinite(nlz).all() and np.isfinite(dnlz).all()
+    for s in (0, 1):  # S = 1: a row of the batch carries the bits of its single evaluation
+        n1, d1 = gp.nll_batch(hyp[s:s + 1], compute_grad=True)
+        assert n1[0] == nlz[s] and np.array_equal(d1[0], dnlz[s]), s
+    n0, _ = gp.nll_batch(hyp, compute_grad=False)
+    assert np.allclose(n0, nlz, rtol=1e-12, atol=0)
+    o0, _ = gp.nll_batch(hyp[1:2], compute_grad=False)
+    assert o0[0] == n0[1]
+    rng = np.random.default_rng(6)
+    v = rng.standard_normal(hyp.shape[1])
+    v /= np.linalg.norm(v)
+    eps = 1e-4
+    pm, _ = gp.nll_batch(np.stack([hyp[0] + eps * v, hyp[0] - eps * v]))
+    num = (pm[0] - pm[1]) / (2 * eps)
+    assert abs(num - dnlz[0] @ v) < 1e-6 * max(1.0, abs(num)), (num, dnlz[0] @ v)
+
+
+def test_n32768_posterior_and_predict():
+    """The posterior path at the same size (factor kept, K* product with a k-major operand of npad x mpad): the predictive
+    mean at training inputs tracks the targets to within the fitted noise, the variance is positive and below the prior's,
+    and one sample of a two-sample posterior set equals the one-sample set bit for bit."""
+    import bench
+
+    N = bench.CONFIGS[6]["N"]
+    X, y, hyp = _problem(N, 2)
+    gp = bench.make_gp(6, "f64")
+    gp.update(X_new=X, y_new=y, hyp=hyp)
+    xs = np.concatenate([X[:200], X[-200:]])
+    mu, s2 = gp.predict(xs, separate_samples=True, add_noise=False)
+    assert np.isfinite(mu).all() and (s2 > 0).all()
+    sf2 = np.exp(2 * hyp[:, 5])
+    assert (s2 < sf2[None, :]).all()
+    resid = mu[:, 0] - np.concatenate([y[:200, 0], y[-200:, 0]])
+    assert np.sqrt(np.mean(resid ** 2)) < 3 * np.exp(hyp[0, 6])  # noise std of sample 0
+    gp1 = bench.make_gp(6, "f64")
+    gp1.update(X_new=X, y_new=y, hyp=hyp[1:2])
+    mu1, s21 = gp1.predict(xs, separate_samples=True, add_noise=False)
+    assert np.array_equal(mu1[:, 0], mu[:, 1]) and np.array_equal(s21[:, 0], s2[:, 1])

@@ -9,7 +9,7 @@ Reference arithmetic being scheduled: gaussian_process.py:2415-2417 (Cholesky), 
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.experiments]  # (the graph lives in the experiments build: conftest.py)
 
 
 @pytest.fixture(scope="module")
@@ -68,14 +68,11 @@ def _both(ctx, N, S, dtype, grad, **opts):
 ])
 def test_graph_equals_stream_order_bit_for_bit(ctx, N, S, dtype, grad, opts):
     ref, got, runs, aborts = _both(ctx, N, S, dtype, grad, **opts)
-    # The two kernels of a graph (GEMM workers, leaf servers) must be resident TOGETHER.  On this stack that is not
-    # guaranteed: now and then the runtime does not start the second launch until the first has ended (seen once in
-    # ~40 graphs, always right after a replayed launch graph on the same stream).  The graph then aborts after its
-    # bounded wait and the stream-ordered schedule answers -- the same bits, which is what is asserted; an abort is
-    # reported, not failed.
-    assert runs >= 1 and aborts <= runs, (runs, aborts)
-    if aborts:
-        print(f"note: {aborts} of {runs} graphs aborted and were answered by the stream-ordered schedule")
+    # The two kernels of a graph (GEMM workers, leaf servers) must be resident TOGETHER, which HIP does not promise (round 5
+    # saw the runtime hold the second launch back once in ~40 graphs; the graph then aborts after its bounded wait and the
+    # stream-ordered schedule answers).  That hazard is why the graph is NOT in the product library; here, in the
+    # experiments build, an abort is a failure again -- the deliberate stall below is the only graph that may abort.
+    assert runs >= 1 and aborts == 0, (runs, aborts)
     assert np.array_equal(ref[0], got[0]), (ref[0], got[0])
     if grad:
         assert np.array_equal(ref[1], got[1], equal_nan=True)

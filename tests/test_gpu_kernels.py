@@ -65,6 +65,7 @@ def test_gemm_modes_fp64(ctx, bt, akm, bkm, M, N, K, klo, khi, lower, alpha, bet
         assert np.array_equal(got[~mask], C0[~mask])
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("akm,bkm", [(0, 0), (0, 1), (1, 1), (1, 0)])
 @pytest.mark.parametrize(
     "M,N,K,klo,khi,lower,alpha,beta",

@@ -313,6 +313,7 @@ def test_nll_only_blocked_solves_every_block_size(ctx):
         bench.CONFIGS[3] = bench_cfg
 
 
+@pytest.mark.experiments
 def test_right_looking_panels_with_lookahead_opt_in(ctx):
     """gpc_set_option("rl_panel", 512): NLL-only evaluations factored right-looking in panels with one panel of
     look-ahead (plan.h: potrf_rl; the trailing update of panel k on a CU-reserving side-stream launch while the next

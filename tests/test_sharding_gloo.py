@@ -263,3 +263,87 @@ def test_eight_ranks_uneven_and_empty_blocks():
     for rank in range(world):
         for S in (2, 7, 16, 13):
             assert res[rank][S] == (True, True, True), (rank, S, res[rank][S])
+
+
+def _rccl_agreement_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import warnings
+
+    import torch.distributed as dist
+
+    from gpyreg_amd import _rccl, sharding
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        made = []
+
+        class FakeComm:
+            """Stands in for _rccl.Comm (which needs RCCL and a GPU): fails where `fail` says, records what happened."""
+            fail = {}
+
+            def __init__(self, group):
+                made.append(self)
+                self.connected = self.destroyed = False
+                if FakeComm.fail.get("init") == rank:
+                    raise RuntimeError("librccl.so: cannot open shared object file")
+
+            def connect(self, group):
+                if FakeComm.fail.get("connect") == rank:
+                    raise RuntimeError("ncclCommInitRank: unhandled system error")
+                self.connected = True
+
+            def destroy(self):
+                self.destroyed = True
+
+        _rccl.Comm = FakeComm
+        res = []
+        warnings.simplefilter("ignore")
+        for case, env_on, fail in [("init fails on rank 1", (True, True), {"init": 1}),
+                                   ("connect fails on rank 0", (True, True), {"connect": 0}),
+                                   ("only rank 0 asks for it", (True, False), {}),
+                                   ("nobody asks", (False, False), {}),
+                                   ("everything works", (True, True), {})]:
+            os.environ["GPYREG_AMD_EXCHANGE"] = "rccl" if env_on[rank] else "torch"
+            _rccl._state["failed"] = False
+            FakeComm.fail = fail
+            del made[:]
+            g = dist.new_group([0, 1])
+            got = _rccl.comm_for(g)
+            again = _rccl.comm_for(g)  # decided once per group: no second agreement (it would need the peer)
+            res.append((case, got is not None, again is got, [m.destroyed for m in made]))
+            # whatever was decided, the exchange itself works on this group afterwards
+            rows, _ = sharding.gather_rows(4, 2, lambda lo, hi: (np.arange(lo, hi)[:, None] * np.ones((1, 2)),
+                                                                 np.zeros(hi - lo, bool)), group=g)
+            assert rows[:, 0].tolist() == [0.0, 1.0, 2.0, 3.0]
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_direct_exchange_falls_back_on_every_rank_or_none():
+    """gpyreg_amd/_rccl.py: whether a process group takes the direct RCCL exchange is agreed by ALL its ranks (all-reduce
+    MIN of a success flag after every stage of the set-up).  With a failure forced on ONE rank -- or the option set on one
+    rank only -- BOTH ranks must come back with "torch path" (a rank that fell back alone would leave its peer waiting in
+    ncclAllGather: VERDICT r5 item 6), a half-made communicator is destroyed, and when nothing fails both take it."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_agreement_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        by_case = {c: (direct, cached, destroyed) for c, direct, cached, destroyed in res[rank]}
+        for c in ("init fails on rank 1", "connect fails on rank 0", "only rank 0 asks for it", "nobody asks"):
+            assert by_case[c][0] is False and by_case[c][1], (rank, c)  # the torch path on EVERY rank
+        assert by_case["everything works"][0] is True and by_case["everything works"][1]
+        assert by_case["connect fails on rank 0"][2] == [True]  # the half-made communicator was destroyed on both ranks
+        assert by_case["everything works"][2] == [False]
+    # "init fails on rank 1": rank 0 had made its half (stage one worked there) and destroyed it; rank 1's raised in __init__
+    assert res[0][0][0] == "init fails on rank 1" and res[0][0][3] == [True] and res[1][0][3] == [False]
