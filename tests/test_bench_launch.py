@@ -232,8 +232,9 @@ def test_the_alone_figure_of_a_batch_that_runs_as_two_sample_groups():
     """`roofline.alone` times the dominant launch in extra steps with ONE sample group; a batch beyond S (N_pad/4096)^3 = 64
     runs its timed steps as TWO groups (two W^T W launches of S/2 samples each).  The alone figure must be priced with the
     flops of the launch it timed (all S samples), not with the timed loop's per-group flops -- round 5 read 0.45 for a
-    launch that ran at 0.90.  N = 4096, 80 samples."""
-    r, line = _bench("--config", "3", "--samples", "80", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
+    launch that ran at 0.90.  cfg5's size, N = 8192, with 16 samples (S (N_pad/4096)^3 = 128: two groups
+    of 8; beyond N_pad = 4096 the one-group pipeline is issued eagerly, so its launch carries events)."""
+    r, line = _bench("--config", "5", "--samples", "16", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
     assert r.returncode == 0, r.stderr[-3000:]
     roof = line["roofline"]
     alone = roof["alone"]
