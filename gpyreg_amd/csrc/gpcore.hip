@@ -11,6 +11,7 @@
 #include "../../include/gpcore.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -443,6 +444,15 @@ struct gpc_ctx {
 #endif
   int stable = 0;        // option: every factorization in stable mode (plan.h), not only the jitter retries
   int small_path = 1;    // option: problems of one 128 x 128 leaf take the two-launch pipeline (Pipe::small_section)
+  // One-leaf evaluations without gradient (round 6): the host watches a word of a COHERENT pinned block that the last
+  // block of the call writes, instead of hipStreamSynchronize (the runtime's completion path costs several microseconds
+  // after the kernel's last store), and the four timing events of a call -- each a barrier packet on the stream -- are
+  // recorded only when "small_timing" is set (gpc_last_timing then reports the device section; 0 otherwise).
+  int small_poll = 1, small_timing = 0;
+  double* land_blk = nullptr;            // hipHostMallocCoherent, LAND_BYTES
+  static constexpr size_t LAND_BYTES = 64u << 10;
+  unsigned long long land_seq = 0;
+  unsigned long long small_polled = 0, small_synced = 0;  // statistics ("small_polled" / "small_synced")
   int check_queues = 0;  // debug option: verify after every pipeline that the tile queues of its persistent launches were drained
   hipEvent_t ev_up = nullptr, ev_done[MAXG] = {};
   int groups = 2;
@@ -1425,9 +1435,16 @@ struct Pipe {
     int* d_info = reinterpret_cast<int*>(d_quad + cnt);
     // (without gradient -- an evaluation, or a posterior: L in A, W and alpha are what it keeps -- the three scalars of a
     // sample are all that comes back)
-    double* land = mode != MODE_GRAD ? static_cast<double*>(c->pin.alloc(scal_bytes)) : nullptr;
+    // (the landing block: the context's coherent block when the results fit and polling is on -- its last word is the
+    // completion flag --, else a piece of the staging block and a stream synchronisation)
+    const bool poll = mode != MODE_GRAD && c->small_poll && c->land_blk && scal_bytes + 16 <= gpc_ctx::LAND_BYTES && cnt <= 64;
+    double* land = mode != MODE_GRAD ? (poll ? c->land_blk : static_cast<double*>(c->pin.alloc(scal_bytes))) : nullptr;
+    unsigned long long* flag = poll ? reinterpret_cast<unsigned long long*>(c->land_blk + (gpc_ctx::LAND_BYTES / 8 - 1)) : nullptr;
+    const unsigned long long seq = ++c->land_seq;
+    int* done_ctr = reinterpret_cast<int*>(reinterpret_cast<char*>(c->scal.p) + scal_bytes);  // zeroed with the scalars
+    const bool timing = c->small_timing != 0;
     XferDesc u;
-    HIPCHK(c, c->pin.take_up(st, c->scal.p, scal_bytes, u));
+    HIPCHK(c, c->pin.take_up(st, c->scal.p, scal_bytes + 8, u));
     u.X = c->dX.as<double>();
     u.mul = hmul;
     u.dv = hdv;
@@ -1436,13 +1453,13 @@ struct Pipe {
     u.npad = npad;
     u.D = D;
     u.cnt = cnt;
-    HIPCHK(c, hipEventRecord(c->ev[1], st));
+    if (timing) HIPCHK(c, hipEventRecord(c->ev[1], st));
     GPC_COV_DISPATCH(small_front_kernel, T, b.cd, dim3(3, cnt), dim3(256), 0, st, u, b.cd, hsp, hdvec, b.vec_noise ? 1 : 0,
                      A, sM);
     hipLaunchKernelGGL((leaf_solve_kernel<T>), dim3(cnt), dim3(256), 0, st, A, sM, npad, W, sM, npad, d_logdet, d_info, N,
                        gpc::g_leaf_fault, rsrc, c->zvec.as<double>(), d_quad,
                        mode != MODE_NLL ? c->avec.as<double>() : nullptr, (const double*)c->spb.as<double>(),
-                       (int)SP_STRIDE, (int)SP_SL, land, cnt);
+                       (int)SP_STRIDE, (int)SP_SL, land, cnt, flag, seq, done_ctr);
     HIPCHK(c, hipGetLastError());
     c->last_flops += (2.0 / 3.0) * TILE * (double)TILE * TILE * cnt;
     if (mode == MODE_GRAD) {
@@ -1471,10 +1488,10 @@ struct Pipe {
                          nN ? (const double*)c->dsn2b.as<double>() : nullptr, nN, (const double*)diagq,
                          nN ? c->ng.as<double>() : nullptr, npad);
       HIPCHK(c, hipGetLastError());
-    } else {
+    } else if (timing) {
       HIPCHK(c, hipEventRecord(c->ev[2], st));
     }
-    HIPCHK(c, hipEventRecord(c->ev[3], st));
+    if (timing) HIPCHK(c, hipEventRecord(c->ev[3], st));
     hc.lap("launch");
     std::vector<double> hscal(scal_bytes / 8);
     if (mode == MODE_GRAD) {
@@ -1487,7 +1504,30 @@ struct Pipe {
     } else if (!land) {
       HIPCHK(c, hipMemcpyAsync(hscal.data(), d_logdet, scal_bytes, hipMemcpyDeviceToHost, st));
     }
-    HIPCHK(c, hipStreamSynchronize(st));
+    bool seen = false;
+    if (poll && !timing) {
+      // (bounded: a call that has not announced itself after 150 us -- a large batch, a busy device -- is waited for the
+      // ordinary way, which also covers a device that never writes the word)
+      const volatile unsigned long long* fw = flag;
+      const auto t_poll = std::chrono::steady_clock::now();
+      for (int spin = 0; !seen; ++spin) {
+        if (*fw == seq) {
+          seen = true;
+          break;
+        }
+        if ((spin & 63) == 63 &&
+            std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_poll).count() > 150.0)
+          break;
+        __builtin_ia32_pause();
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (seen) {
+      ++c->small_polled;  // every store of the call is visible (the flag was its last); the stream drains by itself
+    } else {
+      HIPCHK(c, hipStreamSynchronize(st));
+      ++c->small_synced;
+    }
     c->pin.finish();
     if (land) memcpy(hscal.data(), land, scal_bytes);
     memcpy(&logdet[s0], hscal.data(), (size_t)cnt * 8);
@@ -1504,11 +1544,13 @@ struct Pipe {
                  std::to_string(s0 + i) + "); the results of this call are invalid";
         return -3;
       }
-    float t03 = 0, t12 = 0;
-    (void)hipEventElapsedTime(&t03, c->ev[0], c->ev[3]);
-    (void)hipEventElapsedTime(&t12, c->ev[1], c->ev[2]);
-    c->ms_total += t03;
-    c->ms_factor += t12;
+    if (timing) {
+      float t03 = 0, t12 = 0;
+      (void)hipEventElapsedTime(&t03, c->ev[0], c->ev[3]);
+      (void)hipEventElapsedTime(&t12, c->ev[1], c->ev[2]);
+      c->ms_total += t03;
+      c->ms_factor += t12;
+    }
     return 0;
   }
 
@@ -1589,7 +1631,10 @@ struct Pipe {
     c->pin.begin();
     c->pin.begin_gather();
     auto up = [&](void* dst, const void* src, size_t n) { return c->pin.stage(dst, src, n); };
-    HIPCHK(c, hipEventRecord(c->ev[0], st));
+    // (a one-leaf evaluation records its timing events only on request: each is a barrier packet on a 45 us pipeline)
+    const bool small_cand = c->small_path && npad == TILE && !kmode() && !(stable || c->stable) && gpc::g_leaf_version == 5;
+    bool ev0_pending = small_cand && !c->small_timing;
+    if (!ev0_pending) HIPCHK(c, hipEventRecord(c->ev[0], st));
     const void* hsp = up(c->spb.p, &b.sp[(size_t)s0 * SP_STRIDE], (size_t)cnt * SP_STRIDE * 8);
     const void* hmul = up(c->mulb.p, &b.mul[(size_t)s0 * D], (size_t)cnt * D * 8);
     const void* hdv = up(c->divb.p, &b.dv[(size_t)s0 * D], (size_t)cnt * D * 8);
@@ -1608,8 +1653,7 @@ struct Pipe {
     }
     // Problems that are ONE 128 x 128 leaf take a pipeline of their own (small_section below); there the diagonal term
     // is read from its staged host copy by the build itself and needs no device copy
-    const bool small_ok = c->small_path && npad == TILE && !kmode() && !(stable || c->stable) &&
-                          gpc::g_leaf_version == 5 && hsp && hmul && hdv;
+    const bool small_ok = small_cand && hsp && hmul && hdv;
     // The diagonal term and r = y - m.  Scalar noise / a constant mean (gpc_nll_batch_cm) are ONE value per sample:
     // they are staged as such and expanded on the device by the upload kernel (no S x N arrays cross the bus).
     const void* hdvec = nullptr;
@@ -1680,6 +1724,7 @@ struct Pipe {
       return rc;
     }
     // one kernel: every staged segment and the zeroing of [logdet | quad | info] (padded to whole words)
+    if (ev0_pending) HIPCHK(c, hipEventRecord(c->ev[0], st));  // (a one-leaf candidate that takes the general pipeline after all)
     HIPCHK(c, c->pin.flush_up(st, c->scal.p, scal_bytes0));
 
     hc.lap("h2d");
@@ -2861,6 +2906,17 @@ int gpc_create(int device, gpc_ctx** out) {
     delete c;
     return -1;
   }
+  {  // the landing block of one-leaf evaluations: coherent (fine-grained) host memory, so that a word the device writes
+     // in the middle of a kernel is seen by a polling host; without it those calls wait on the stream as before
+    void* lp = nullptr;
+    if (hipHostMalloc(&lp, gpc_ctx::LAND_BYTES, hipHostMallocCoherent) == hipSuccess) {
+      memset(lp, 0, gpc_ctx::LAND_BYTES);
+      c->land_blk = static_cast<double*>(lp);
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  if (const char* e = getenv("GPC_SMALL_POLL")) c->small_poll = atoi(e) != 0;
   if (probe_cu_map(c, prop.multiProcessorCount) != 0 || build_reserve_table(c) != 0) {
     g_create_err = "probing the CU map failed: " + c->err;
     delete c;
@@ -2896,6 +2952,7 @@ void gpc_destroy(gpc_ctx* c) {
   for (DevBuf* b : bufs) b->release();
   c->pool_drain();
   c->pin.release();
+  if (c->land_blk) (void)hipHostFree(c->land_blk);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
   if (c->ev_up) (void)hipEventDestroy(c->ev_up);
@@ -3417,6 +3474,10 @@ int gpc_set_option(gpc_ctx* c, const char* name, int value) {
     c->small_path = value != 0;
   else if (n == "check_queues")  // debug: verify the tile queues of persistent launches after every pipeline
     c->check_queues = value != 0;
+  else if (n == "small_poll")  // 0: one-leaf evaluations wait on the stream instead of polling their landing block
+    c->small_poll = value != 0;
+  else if (n == "small_timing")  // 1: one-leaf evaluations record their timing events (gpc_last_timing is 0 for them otherwise)
+    c->small_timing = value != 0;
   else if (n == "start_mult_log10")  // test hook: first jitter multiplier 10^value
     c->start_mult = std::pow(10.0, std::max(0, std::min(9, value)));
   else if (n == "append_fail_mask")  // test hook: samples whose rank-one append is declared unstable
@@ -3447,6 +3508,10 @@ int gpc_get_option(gpc_ctx* c, const char* name, int* value) {
   else if (n == "stable") *value = c->stable;
   else if (n == "small_path") *value = c->small_path;
   else if (n == "check_queues") *value = c->check_queues;
+  else if (n == "small_poll") *value = c->small_poll;
+  else if (n == "small_timing") *value = c->small_timing;
+  else if (n == "small_polled") *value = (int)(c->small_polled & 0x7fffffff);  // one-leaf calls completed by the polled word ...
+  else if (n == "small_synced") *value = (int)(c->small_synced & 0x7fffffff);  // ... and by a stream synchronisation
   else if (n == "experiments") {  // 1: this library is the experiments build (tests/ and tools/ ask before they use its options)
 #ifdef GPC_EXPERIMENTS
     *value = 1;

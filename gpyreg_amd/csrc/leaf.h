@@ -828,7 +828,8 @@ __global__ __launch_bounds__(256, 1) void leaf5_kernel(T* __restrict__ A, long l
 // that factored the matrix reads its own W back (L2 / L1 hot) and finishes the job:
 //     z = W r,   quad = z.z,   alpha = W^T z / sl  (gradient evaluations only)
 // and, for an evaluation without gradient, writes [logdet | quad | info] of its sample straight into the host's pinned
-// landing block (`land`, mapped memory), so no download kernel follows.   grid = (batch), 256 threads.
+// landing block (`land`, mapped memory), so no download kernel follows -- and, when `flag` is given, announces the call's
+// completion there as well (round 6: the host polls that word instead of waiting for the stream).   grid = (batch), 256 threads.
 template <typename T>
 __global__ __launch_bounds__(256, 1) void leaf_solve_kernel(T* __restrict__ A, long long sA, int lda, T* __restrict__ W,
                                                             long long sW, int ldw, double* __restrict__ logdet,
@@ -836,7 +837,9 @@ __global__ __launch_bounds__(256, 1) void leaf_solve_kernel(T* __restrict__ A, l
                                                             const double* __restrict__ r_all, double* __restrict__ z_all,
                                                             double* __restrict__ quad_all, double* __restrict__ alpha_all,
                                                             const double* __restrict__ sp_all, int sp_stride, int sp_sl,
-                                                            double* __restrict__ land, int cnt) {
+                                                            double* __restrict__ land, int cnt,
+                                                            unsigned long long* __restrict__ flag = nullptr,
+                                                            unsigned long long seq = 0, int* __restrict__ done_ctr = nullptr) {
   using vec_t = typename MM<T>::vec_t;
   constexpr int VEC = MM<T>::VEC;
   __shared__ leaf5::Shared<T> sh;
@@ -904,6 +907,15 @@ __global__ __launch_bounds__(256, 1) void leaf_solve_kernel(T* __restrict__ A, l
       land[b] = ld;
       land[cnt + b] = q;
       reinterpret_cast<int*>(land + 2 * (size_t)cnt)[b] = inf;
+      if (flag) {
+        // The host does not wait for the end-of-kernel signal of the runtime (completion packet, cache write-back,
+        // wake-up: several microseconds after the last instruction) but watches `flag`, a word of the same coherent host
+        // block: every block makes its three values visible system-wide, counts itself, and the block that finds itself
+        // the last one publishes this call's sequence number.
+        __threadfence_system();
+        const int before = __hip_atomic_fetch_add(done_ctr, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (before == cnt - 1) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   }
 }
