@@ -104,3 +104,28 @@ def test_n32768_posterior_and_predict():
     gp1.update(X_new=X, y_new=y, hyp=hyp[1:2])
     mu1, s21 = gp1.predict(xs, separate_samples=True, add_noise=False)
     assert np.array_equal(mu1[:, 0], mu[:, 1]) and np.array_equal(s21[:, 0], s2[:, 1])
+
+
+def test_n65536_more_than_2_31_elements_per_matrix():
+    """N = 65536: every matrix of a sample holds 2^32 elements (34 GB in fp64, three of them per sample) -- beyond a 32-bit
+    ELEMENT index, not only a 32-bit byte offset.  One sample: NLL-only (the N^3/3 plan with blocked solves) equals the NLL
+    of NLL + gradient to rounding, and the gradient agrees with a central difference along a random direction."""
+    import bench
+    from gpyreg_amd import _lib
+
+    N = 65536
+    if _lib.load().gpc_max_n(_lib.F64) < N:
+        pytest.skip("this device's memory does not hold three 34 GB slabs")
+    X, y, hyp = _problem(N, 1)
+    gp = bench.make_gp(6, "f64")
+    gp.update(X_new=X, y_new=y, hyp=hyp[:1], compute_posterior=False)
+    nlz, dnlz = gp.nll_batch(hyp, compute_grad=True)
+    assert np.isfinite(nlz).all() and np.isfinite(dnlz).all()
+    rng = np.random.default_rng(65536)
+    v = rng.standard_normal(hyp.shape[1])
+    v /= np.linalg.norm(v)
+    eps = 1e-4
+    trio, _ = gp.nll_batch(np.stack([hyp[0], hyp[0] + eps * v, hyp[0] - eps * v]), compute_grad=False)
+    assert abs(trio[0] - nlz[0]) <= 1e-11 * abs(nlz[0]), (trio[0], nlz[0])
+    num = (trio[1] - trio[2]) / (2 * eps)
+    assert abs(num - dnlz[0] @ v) < 1e-6 * max(1.0, abs(num)), (num, dnlz[0] @ v)
