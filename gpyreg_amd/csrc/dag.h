@@ -665,7 +665,9 @@ __global__ __launch_bounds__(256) void dag_init_kernel(DagDev d) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     const int s = (int)(i / d.ntasks), t = (int)(i - (long long)s * d.ntasks);
     const int np = d.tasks[t].npred;
-    const bool gated = np == 0 && d.gate > 0 && s >= d.gate;  // (the first leaf is the one task without predecessors)
+    // (only task 0, the first leaf, is gated: its release by sample s - gate re-pushes TASK 0 -- any other root task of a
+    // plan would never be released)
+    const bool gated = t == 0 && np == 0 && d.gate > 0 && s >= d.gate;
     d.pending[i] = np + (gated ? 1 : 0);
     if (np == 0 && !gated) dag_push(d, s, t);
   }

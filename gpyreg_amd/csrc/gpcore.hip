@@ -668,6 +668,20 @@ int probe_cu_map(gpc_ctx* c, int n_cus) {
   return 0;
 }
 
+#ifdef GPC_EXPERIMENTS
+// XCDs the CU probe saw workgroups on: the dataflow graph serves the urgent ring of team x from XCD x only, so it needs all
+// NQ of them (a partitioned device would stall every graph until its time-out: ADVICE r5)
+int xcds_seen(const gpc_ctx* c) {
+  int n = 0;
+  for (int x = 0; x < 8; ++x) {
+    unsigned any = 0;
+    for (int se = 0; se < 8; ++se) any |= c->cu_seen[x * 8 + se];
+    n += any != 0;
+  }
+  return n;
+}
+#endif
+
 // rsv_tbl for `reserve` CUs per XCD: the highest-numbered CUs of each shader engine -- 2: one in every other engine,
 // 4: one per engine, 8: two, 12: three, ...; >= 32 (test hook): every CU, which leaves the work to the one block the
 // survivor rule of cu_reserve_bail keeps.
@@ -1463,7 +1477,9 @@ struct Pipe {
     // sample are all that comes back)
     // (the landing block: the context's coherent block when the results fit and polling is on -- its last word is the
     // completion flag --, else a piece of the staging block and a stream synchronisation)
-    const bool poll = mode != MODE_GRAD && c->small_poll && c->land_blk && scal_bytes + 16 <= gpc_ctx::LAND_BYTES && cnt <= 64;
+    // (a gradient evaluation ends with the gathered download launch instead, which announces itself the same way:
+    // XferDesc::flag)
+    const bool poll = c->small_poll && c->land_blk && scal_bytes + 16 <= gpc_ctx::LAND_BYTES && cnt <= 64;
     double* land = mode != MODE_GRAD ? (poll ? c->land_blk : static_cast<double*>(c->pin.alloc(scal_bytes))) : nullptr;
     unsigned long long* flag = poll ? reinterpret_cast<unsigned long long*>(c->land_blk + (gpc_ctx::LAND_BYTES / 8 - 1)) : nullptr;
     const unsigned long long seq = ++c->land_seq;
@@ -1485,7 +1501,7 @@ struct Pipe {
     hipLaunchKernelGGL((leaf_solve_kernel<T>), dim3(cnt), dim3(256), 0, st, A, sM, npad, W, sM, npad, d_logdet, d_info, N,
                        gpc::g_leaf_fault, rsrc, c->zvec.as<double>(), d_quad,
                        mode != MODE_NLL ? c->avec.as<double>() : nullptr, (const double*)c->spb.as<double>(),
-                       (int)SP_STRIDE, (int)SP_SL, land, cnt, flag, seq, done_ctr);
+                       (int)SP_STRIDE, (int)SP_SL, land, cnt, mode != MODE_GRAD ? flag : nullptr, seq, done_ctr);
     HIPCHK(c, hipGetLastError());
     c->last_flops += (2.0 / 3.0) * TILE * (double)TILE * TILE * cnt;
     if (mode == MODE_GRAD) {
@@ -1526,12 +1542,14 @@ struct Pipe {
       if (mean_N > 0) HIPCHK(c, c->pin.gather(&mg[(size_t)s0 * mean_N], c->mg.p, (size_t)cnt * mean_N * 8, st));
       if (noise_N > 0 && b.vec_noise)
         HIPCHK(c, c->pin.gather(&ng[(size_t)s0 * noise_N], c->ng.p, (size_t)cnt * noise_N * 8, st));
-      HIPCHK(c, c->pin.flush_down(st));
+      const bool fl = poll && !c->pin.down_plain;
+      HIPCHK(c, c->pin.flush_down(st, fl ? flag : nullptr, seq, done_ctr));
+      if (!fl) flag = nullptr;
     } else if (!land) {
       HIPCHK(c, hipMemcpyAsync(hscal.data(), d_logdet, scal_bytes, hipMemcpyDeviceToHost, st));
     }
     bool seen = false;
-    if (poll && !timing) {
+    if (poll && flag && !timing) {
       // (bounded: a call that has not announced itself after 150 us -- a large batch, a busy device -- is waited for the
       // ordinary way, which also covers a device that never writes the word)
       const volatile unsigned long long* fw = flag;
@@ -1794,7 +1812,7 @@ struct Pipe {
     use_dag = false;
     c->dag_used = false;
     if (c->dag != 0 && !dag_off_once && !kmode() && !(stable || c->stable) && mode != MODE_POST && !use_rl &&
-        gpc::g_leaf_version == 5 && c->cu_map_ok && npad >= 2 * TILE && c->dag_aborts < 3) {
+        gpc::g_leaf_version == 5 && c->cu_map_ok && xcds_seen(c) == NQ && npad >= 2 * TILE && c->dag_aborts < 3) {
       use_dag = c->dag > 0 || dag_auto(cnt, npad);
       if (use_dag) {
         groups = 1;

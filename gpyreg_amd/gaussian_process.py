@@ -271,11 +271,11 @@ class GP:
 
         return type(self.mean) in (ZeroMean, ConstantMean)
 
-    def _noise_values(self, hyp: np.ndarray, grad: bool):
+    def _noise_values(self, hyp: np.ndarray, grad: bool, counts=None):
         """The noise part of ``_plugin_values``: sn2, dsn2 | None, per-point flag."""
         from .noise_functions import GaussianNoise
 
-        cov_N, noise_N, _ = self._counts()
+        cov_N, noise_N, _ = counts or self._counts()
         S = hyp.shape[0]
         h_noise = hyp[:, cov_N:cov_N + noise_N]
         dsn2 = None
@@ -366,8 +366,10 @@ class GP:
         S = hyp.shape[0]
         C = 1 + (hyp_N if compute_grad else 0)
 
+        counts = (cov_N, noise_N, mean_N)  # (once per call: three plugin calls each, on the path of every evaluation)
+
         def local(lo, hi):
-            nlz, dnlz, info = self._nll_batch_local(hyp[lo:hi], compute_grad)
+            nlz, dnlz, info = self._nll_batch_local(hyp[lo:hi], compute_grad, counts)
             rows = nlz[:, None] if not compute_grad else np.concatenate([nlz[:, None], dnlz], axis=1)
             return rows, info != 0
 
@@ -380,15 +382,15 @@ class GP:
         return full[:, 0].copy(), (full[:, 1:].copy() if compute_grad else None)
 
     @_on_device
-    def _nll_batch_local(self, hyp, compute_grad):
+    def _nll_batch_local(self, hyp, compute_grad, counts=None):
         """This rank's evaluation of the rows of ``hyp``: nlZ, dnlZ | None, info (no exception for a
         failed sample: the caller decides, after the exchange when sharded)."""
-        cov_N, noise_N, mean_N = self._counts()
+        cov_N, noise_N, mean_N = counts = counts or self._counts()
         ctx = self._ctx()
         if self._builtin and self._const_mean():
             # the stock zero / constant mean: one value per sample crosses the boundary (gpc_nll_batch_cm), not an
             # (S, N) array of copies of it and an (S, N, 1) array of ones -- same results, to the bit
-            sn2, dsn2, vec = self._noise_values(hyp, compute_grad)
+            sn2, dsn2, vec = self._noise_values(hyp, compute_grad, counts)
             kid, deg = self._kid()
             m0 = hyp[:, cov_N + noise_N] if mean_N == 1 else None
             nlz, dnlz, mult, lchol, info = ctx.nll_batch_cm(

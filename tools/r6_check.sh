@@ -21,3 +21,5 @@ unset GPYREG_AMD_LIB
 step 400 bench_cfg3.json python bench.py --steps 20 --warmup 5
 step 300 bench_cfg3_S2.json python bench.py --steps 20 --warmup 5 --samples 2 --no-cpu-baseline
 step 600 bench_cfg6.json python bench.py --config 6 --steps 3 --warmup 1
+step 200 small_n_probe.txt python tools/small_n_probe.py
+head -6 $O/small_n_probe.txt
