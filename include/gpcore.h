@@ -188,7 +188,8 @@ int gpc_quad(gpc_post* post, const double* mu, const double* sigma, int M, int c
 /* ---- instrumentation -------------------------------------------------------------
  * GPU time (ms, hipEvent on the library's stream) of the last gpc_nll_batch /
  * gpc_posterior_batch: whole device section, and the part spent in the MFMA GEMM
- * launches + leaf factorizations (the N^3 work).                                    */
+ * launches + leaf factorizations (the N^3 work).  Calls below N_pad = 2048 record
+ * these events only under gpc_set_option(ctx, "small_timing", 1): both are 0 otherwise. */
 int gpc_last_timing(gpc_ctx* ctx, double* ms_total, double* ms_factor);
 /* (after gpc_predict / gpc_predict_full / gpc_quad: ms_total = device time of the call, ms_factor = the
  * duration of its N^2 M product V = W Ks, the GEMM launch of gaussian_process.py:1752-1760)            */
@@ -204,7 +205,13 @@ int gpc_last_lauum_timing(gpc_ctx* ctx, double* ms, double* flops);
  * "defer_reserve" = CUs per XCD that launch keeps empty (2 | 4 | 8 | 12).  Test hooks:
  * "start_mult_log10" = k starts the jitter escalation of every factorization at 10^k instead of 1
  * (gaussian_process.py:2402), "append_fail_mask" = bit s declares the rank-one append of sample s
- * unstable (:789-798).  "experiments" (get only): 1 when the loaded library is the experiments build.   */
+ * unstable (:789-798).  "experiments" (get only): 1 when the loaded library is the experiments build.
+ * Round 6, calls below N_pad = 2048 (single evaluations of the sampler and the optimiser on small training sets:
+ * slice_sample.py:442, gaussian_process.py:1540): "small_poll" (default 1) = the call returns when a word that its last
+ * launch writes into coherent host memory shows up, instead of waiting for the stream (bounded: after 0.15 - 2 ms it waits
+ * for the stream after all); "small_timing" (default 0) = such calls record their timing events, so that gpc_last_timing
+ * reports their device section (it reports 0 for them otherwise; from N_pad = 2048 on the events are always recorded).
+ * "small_polled" / "small_synced" (get only): how many calls ended either way.                                         */
 int gpc_set_option(gpc_ctx* ctx, const char* name, int value);
 /* Current value of a tuning switch (so that a caller that changes one for a measurement can put it back). */
 int gpc_get_option(gpc_ctx* ctx, const char* name, int* value);

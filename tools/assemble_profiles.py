@@ -105,6 +105,33 @@ for n in sorted(acc1):
         line = f"  {n[:62]:62s} {100 * acc1[n] / (acc3[n] / 8 * 1024):5.1f} %   {ms.get(n, float('nan')):6.2f} ms per step"
         out.write(line + "\n")
         print(line)
+# Per LAUNCH, the persistent 128-tile classes of one step (which launches of the 77.8 % class lose the
+# time).  The PMC passes serialise kernels, so a CU-reserving launch (grid 512 + 96: U = T21 W11 of the top two levels)
+# runs ALONE here on 192 of the 256 CUs -- its utilisation is quoted against the chip and against the CUs it may use.
+rows_by_d = collections.OrderedDict()
+for r in load("pmc1"):
+    n = r["Kernel_Name"].replace("void gpc::", "").split("(")[0]
+    if "gemm_persist_kernel" not in n:
+        continue
+    e = rows_by_d.setdefault(int(r["Dispatch_Id"]), {"name": n, "wg": int(r["Grid_Size"]) // int(r["Workgroup_Size"]),
+                                                     "ms": (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6})
+    e[r["Counter_Name"]] = e.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+out.write("\nper launch, persistent 128-tile GEMM classes (first step of the pmc1 pass; kernels run serialised under --pmc):\n"
+          "  dispatch  kernel                                                  workgroups      ms   MFMA busy of the chip   of the CUs it may use   TFLOP/s (MOPS_F64 x 512 / ms)\n")
+first = None
+for did, e in rows_by_d.items():
+    if "true, true" in e["name"]:
+        first = did if first is None else first
+    if first is not None and did > first:
+        break  # one step: up to and including its W^T W launch
+    sqb = e.get("SQ_BUSY_CYCLES", 0.0)
+    util = e.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (sqb * 32.0) if sqb else float("nan")  # 32 SIMDs per shader engine
+    reserved = e["wg"] > 2 * 256
+    tf = e.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0) * 512.0 / (e["ms"] * 1e-3) / 1e12
+    line = (f"  {did:8d}  {e['name'][:54]:54s}  {e['wg']:10d}  {e['ms']:6.3f}   {100 * util:20.1f} %   "
+            f"{100 * util / (0.75 if reserved else 1.0):19.1f} %{' (192 CUs)' if reserved else '          '}   {tf:8.1f}")
+    out.write(line + "\n")
+    print(line)
 nsteps = 5
 tot_f = sum(float(r["Counter_Value"]) for r in load("pmc2") if r["Counter_Name"] == "FETCH_SIZE")
 tot_w = sum(float(r["Counter_Value"]) for r in load("pmc3") if r["Counter_Name"] == "WRITE_SIZE")

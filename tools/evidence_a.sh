@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-4 evidence, part A (GPU box, repo root):  bash tools/evidence_a.sh <run-tag> <profiles-tag>
+# Evidence of a round, part A (GPU box, repo root):  bash tools/evidence_a.sh <run-tag> <profiles-tag>
 #   GPU tests -> smoke -> rocprofv3 kernel stats + the three PMC passes of the cfg3 bench -> profiles/<ptag>_* assembled ON
 #   THE BOX (so that the traffic file exists before the tracked line is taken) -> the tracked bench line (it then quotes
 #   the PMC traffic of its own code state).  Everything lands under gpurun_out/<run-tag>/ (profiles/ in its subdirectory).

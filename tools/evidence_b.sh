@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-4 evidence, part B: the other configurations and modes.  bash tools/evidence_b.sh <run-tag> <profiles-tag>
+# Evidence of a round, part B: the other configurations and modes.  bash tools/evidence_b.sh <run-tag> <profiles-tag>
 set -o pipefail
 TAG=${1:?usage: evidence_b.sh <run-tag> <profiles-tag>}; PTAG=${2:?profiles tag}
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/$TAG
@@ -9,9 +9,10 @@ b() { out=$1; shift; timeout -k 10 500 python bench.py "$@" > $O/profiles/${PTAG
 b bench_cfg3_nll --mode nll --steps 20 --warmup 5
 b bench_cfg2 --config 2 --steps 50 --warmup 10
 b bench_cfg5 --config 5 --steps 3 --warmup 1
+b bench_cfg6 --config 6 --steps 3 --warmup 1
 b bench_predict_cfg3 --mode predict --steps 20 --warmup 5
 b bench_predict_cfg5 --mode predict --config 5 --steps 5 --warmup 2
-for S in 2 4 8; do b bench_cfg3_S$S --samples $S --steps 20 --warmup 5 --no-cpu-baseline; done
+for S in 1 2 4 8; do b bench_cfg3_S$S --samples $S --steps 20 --warmup 5 --no-cpu-baseline; done
 b bench_cfg5_S8 --config 5 --samples 8 --steps 5 --warmup 2 --no-cpu-baseline
 b bench_cfg3_2ranks_gloo_one_gpu --gpus 2 --backend gloo --steps 10 --warmup 3
 (cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_predict -- python3 $R/bench.py --mode predict --steps 5 --warmup 2 --no-cpu-baseline > $O/prof_predict.log 2>&1; echo "rocprof predict exit=$?")
