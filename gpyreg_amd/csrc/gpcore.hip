@@ -182,7 +182,8 @@ __global__ __launch_bounds__(256) void xfer_kernel(XferDesc d) {
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {
-      const int before = __hip_atomic_fetch_add(d.done_ctr, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      // (done_ctr == nullptr: a launch of ONE workgroup -- it is its own last one)
+      const int before = d.done_ctr ? __hip_atomic_fetch_add(d.done_ctr, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) : 0;
       if (before == (int)gridDim.x - 1) __hip_atomic_store(d.flag, d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
@@ -412,7 +413,8 @@ struct PinBuf {
     if (downd.nseg == 0) return hipSuccess;
     unsigned long long words = 0;
     for (int k = 0; k < downd.nseg; ++k) words += downd.seg[k].n8;
-    const int blocks = (int)std::min<unsigned long long>(64, (words + 255) / 256);
+    int blocks = (int)std::min<unsigned long long>(64, (words + 255) / 256);
+    if (flag && !done_ctr) blocks = 1;  // (no zeroed counter at hand: one workgroup moves the few KB and announces itself)
     downd.flag = flag;
     downd.seq = seq;
     downd.done_ctr = done_ctr;
@@ -2395,6 +2397,11 @@ int rhs_products(gpc_post* po, int mode, const double* xa, const double* xb, int
   double* d_xa = c->xss.as<double>() + (size_t)chunk * mpad * D;
   double* d_xb = d_xa + (size_t)M * D;
   c->pin.begin();
+  c->pin.begin_gather();
+  // (round 6, as for the evaluations: below N_pad = 2048 -- the posterior of a small training set queried in a loop by an
+  // acquisition function -- timing events are recorded on request only and the call returns on the polled word of its
+  // download launch)
+  const bool timing_on = c->small_timing != 0 || npad >= 2048;
   if (mode != 2) {
     HIPCHK(c, c->pin.up(d_xa, xa, (size_t)M * D * 8, st));
     if (xb) HIPCHK(c, c->pin.up(d_xb, xb, (size_t)M * D * 8, st));
@@ -2438,7 +2445,7 @@ int rhs_products(gpc_post* po, int mode, const double* xa, const double* xb, int
   c->ms_total = c->ms_factor = 0;
   for (int s0 = 0; s0 < S; s0 += chunk) {
     const int cnt = std::min(chunk, S - s0);
-    HIPCHK(c, hipEventRecord(c->ev[0], st));
+    if (timing_on) HIPCHK(c, hipEventRecord(c->ev[0], st));
     if (!resident) {
       HIPCHK(c, hipMemcpyAsync(c->spb.p, &po->sp[(size_t)s0 * SP_STRIDE], (size_t)cnt * SP_STRIDE * 8,
                                hipMemcpyHostToDevice, st));
@@ -2494,8 +2501,10 @@ int rhs_products(gpc_post* po, int mode, const double* xa, const double* xb, int
     HIPCHK(c, hipGetLastError());
     // runs of equal L_chol share launches
     int a = 0;
-    HIPCHK(c, hipEventRecord(c->ev[1], st));
-    HIPCHK(c, hipEventRecord(c->ev[2], st));
+    if (timing_on) {
+      HIPCHK(c, hipEventRecord(c->ev[1], st));
+      HIPCHK(c, hipEventRecord(c->ev[2], st));
+    }
     while ((want_quad || full) && a < cnt) {
       int e = a;
       while (e < cnt && po->lchol[s0 + e] == po->lchol[s0 + a]) ++e;
@@ -2528,17 +2537,17 @@ int rhs_products(gpc_post* po, int mode, const double* xa, const double* xb, int
         HIPCHK(c, c->dbg3.ensure((size_t)cnt * tm * mpad * 8));  // (the whole chunk: no reallocation between runs)
         int* qctr = c->tile_ctr.as<int>() + (size_t)gpc_ctx::MAXG * gpc_ctx::CTR_PER_GROUP;
         HIPCHK(c, hipMemsetAsync(qctr, 0, CTR_STRIDE * sizeof(int), st));
-        HIPCHK(c, hipEventRecord(c->ev[1], st));
+        if (timing_on) HIPCHK(c, hipEventRecord(c->ev[1], st));
         g.colsq = c->dbg3.as<double>();
         HIPCHK(c, launch_gemm_colsq<T>(st, g, len, qctr));
-        if (e == cnt) HIPCHK(c, hipEventRecord(c->ev[2], st));
+        if (e == cnt && timing_on) HIPCHK(c, hipEventRecord(c->ev[2], st));
         hipLaunchKernelGGL(colpart_reduce_kernel, dim3((mpad + 255) / 256, len), dim3(256), 0, st,
                            (const double*)c->dbg3.as<double>(), tm, mpad, d_v + (size_t)a * mpad);
         a = e;
         continue;
       }
       HIPCHK(c, launch_gemm<T>(st, g, false, true, len));
-      if (e == cnt) HIPCHK(c, hipEventRecord(c->ev[2], st));  // (several runs: the first launch to the last, with what lies between)
+      if (e == cnt && timing_on) HIPCHK(c, hipEventRecord(c->ev[2], st));  // (several runs: the first launch to the last, with what lies between)
       const T* left = lch ? (const T*)(V + (size_t)a * sKs) : (const T*)(Ks + (size_t)a * sKs);
       hipLaunchKernelGGL((colsum_prod_kernel<T>), dim3(mpad / 64, len), dim3(256), 0, st, left, sKs,
                          (const T*)(V + (size_t)a * sKs), sKs, mpad, npad, mpad, d_v + (size_t)a * mpad);
@@ -2564,7 +2573,11 @@ int rhs_products(gpc_post* po, int mode, const double* xa, const double* xb, int
       a = e;
     }
     HIPCHK(c, hipGetLastError());
-    if (want_quad && cnt == chunk)  // d_v = d_mu + chunk * mpad: one contiguous block
+    const size_t out_bytes = (want_quad ? 2 : 1) * (size_t)chunk * mpad * 8;
+    const bool poll = !timing_on && !full && c->small_poll && c->land_blk && cnt == chunk && out_bytes <= PinBuf::kGather / 8;
+    if (poll) {  // the results through the gathered download launch, which carries the completion word
+      HIPCHK(c, c->pin.gather(hmu, d_mu, want_quad ? out_bytes : (size_t)cnt * mpad * 8, st));
+    } else if (want_quad && cnt == chunk)  // d_v = d_mu + chunk * mpad: one contiguous block
       HIPCHK(c, hipMemcpyAsync(hmu, d_mu, 2 * (size_t)chunk * mpad * 8, hipMemcpyDeviceToHost, st));
     else {
       HIPCHK(c, hipMemcpyAsync(hmu, d_mu, (size_t)cnt * mpad * 8, hipMemcpyDeviceToHost, st));
@@ -2582,9 +2595,36 @@ int rhs_products(gpc_post* po, int mode, const double* xa, const double* xb, int
         if (hfull) memcpy(dst, hfull, (size_t)M * M * 8);
       }
     }
-    HIPCHK(c, hipEventRecord(c->ev[3], st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    {
+    if (timing_on) HIPCHK(c, hipEventRecord(c->ev[3], st));
+    bool seen = false;
+    if (poll && !c->pin.down_plain) {
+      unsigned long long* flag = reinterpret_cast<unsigned long long*>(c->land_blk + (gpc_ctx::LAND_BYTES / 8 - 1));
+      const unsigned long long seq = ++c->land_seq;
+      HIPCHK(c, c->pin.flush_down(st, flag, seq, nullptr));
+      const volatile unsigned long long* fw = flag;
+      const auto t_poll = std::chrono::steady_clock::now();
+      for (int spin = 0; !seen; ++spin) {
+        if (*fw == seq) {
+          seen = true;
+          break;
+        }
+        if ((spin & 63) == 63 &&
+            std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_poll).count() > 2000.0)
+          break;
+        __builtin_ia32_pause();
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+    } else if (poll) {
+      HIPCHK(c, c->pin.flush_down(st));
+    }
+    if (seen) {
+      ++c->small_polled;
+    } else {
+      HIPCHK(c, hipStreamSynchronize(st));
+      if (poll) ++c->small_synced;
+    }
+    c->pin.finish();
+    if (timing_on) {
       float t03 = 0, t12 = 0;
       (void)hipEventElapsedTime(&t03, c->ev[0], c->ev[3]);
       (void)hipEventElapsedTime(&t12, c->ev[1], c->ev[2]);

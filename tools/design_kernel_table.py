@@ -36,7 +36,7 @@ def util(tagname):
 
 ROLE = [
     ("gemm_persist_kernel<double, true, true", "W^T W = (K + sn2 I)^-1, all samples in one persistent launch", "fp64 MFMA", "F = S N^3 / 3"),
-    ("gemm_persist_kernel<double, false, true", "U = T21 W11 and W21 = -W22 U of the top levels (the deferred launch runs on 192 of 256 CUs)", "fp64 MFMA", ""),
+    ("gemm_persist_kernel<double, false, true", "U = T21 W11 (three CU-reserving launches on 192 of 256 CUs: 96.7 % / 85.6 % MFMA-busy on THOSE CUs, per-launch table in the pmc summary) and W21 = -W22 U of the root (whole chip: 96.8 %)", "fp64 MFMA", ""),
     ("gemm_persist_kernel<double, false, false", "T21 = A21 W11^T and the syrk updates of the top levels", "fp64 MFMA", ""),
     ("gemm_kernel<double, false, false, 64", "the same products at the 1024 / 512 levels as 64-tile launches", "fp64 MFMA (L2-bound in practice)", ""),
     ("gemm_kernel<double, false, true, 64", "inverse products of those levels", "fp64 MFMA (L2-bound in practice)", ""),
