@@ -49,7 +49,7 @@ int gpc_set_data(gpc_ctx* ctx, const double* X, const double* y, int N, int D);
 int gpc_cov_count(int kernel_id, int D);
 /* Largest N the dense stages accept for a dtype: a MEMORY-BUDGET answer (round 6) -- the largest multiple of 128 whose
  * three padded N x N slabs of one sample (matrix / factor, inverse factor, scratch) fit in 80 % of the current device's
- * memory (fp64 on a 288 GB MI355X: 97 920; fp32: 138 496).  The reference factorizes whatever fits host memory
+ * memory (fp64 on a 288 GB MI355X: 101 504; fp32: 143 488).  The reference factorizes whatever fits host memory
  * (gaussian_process.py:2415-2417, :2477-2484); so does this library with device memory.  (Rounds 1-5 answered 16384 /
  * 23168: one 32-bit byte offset spanned a k-major operand panel.  The GEMM now advances a 64-bit base per k-slab.)
  * The batch entry points return -2 above it.  Without a visible device the answer assumes 288 GB.                       */

@@ -1,5 +1,5 @@
 """The size envelope, exercised: one NLL + gradient evaluation and one NLL-only evaluation at N = gpc_max_n(fp64) (97 920 on
-a 288 GB MI355X: three slabs of 76.7 GB), SE kernel, D = 5 -- finite results, NLL-only == NLL of NLL + gradient to rounding,
+a 288 GB MI355X: three slabs of 82.4 GB), SE kernel, D = 5 -- finite results, NLL-only == NLL of NLL + gradient to rounding,
 wall clock and the fraction of the fp64 MFMA peak.   usage: python tools/max_n_probe.py [N]   (GPU box; ~1 minute)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
