@@ -154,3 +154,40 @@ def test_n32768_fp32_properties():
     assert np.abs(n32 - n64).max() <= 1e-3 * np.abs(n64).max(), (n32, n64)
     assert np.abs(m32 - n64).max() <= 1e-3 * np.abs(n64).max(), (m32, n64)
     assert (np.abs(d32 - d64) / np.maximum(np.abs(d64), np.abs(d64).max(1, keepdims=True))).max() <= 1e-3
+
+
+def test_beyond_the_envelope_is_refused_before_anything_is_allocated():
+    """N above gpc_max_n: the batch entry points answer -2 with a message about the device's memory (no allocation is
+    attempted, the context stays usable) -- the one size limit left, and it is the device's, not an addressing mode's."""
+    import gpyreg_amd as gpr
+    from gpyreg_amd import _lib
+
+    n_max = _lib.load().gpc_max_n(_lib.F64)
+    N, D = n_max + 128, 2
+    rng = np.random.default_rng(1)
+    X = rng.uniform(-3, 3, (N, D))
+    y = np.sin(X.sum(1, keepdims=True))
+    hyp = np.array([[0.5, 0.5, 0.0, np.log(0.1), 0.0]])
+    gp = gpr.GP(D, gpr.covariance_functions.SquaredExponential(), gpr.mean_functions.ConstantMean(),
+                gpr.noise_functions.GaussianNoise(constant_add=True))
+    gp.update(X_new=X, y_new=y, hyp=hyp, compute_posterior=False)
+    with pytest.raises(RuntimeError) as e:
+        gp.nll_batch(hyp, compute_grad=False)
+    assert "memory" in str(e.value) and "gpc_max_n" in str(e.value)
+    small = gpr.GP(D, gpr.covariance_functions.SquaredExponential(), gpr.mean_functions.ConstantMean(),
+                   gpr.noise_functions.GaussianNoise(constant_add=True))
+    small.update(X_new=X[:300], y_new=y[:300], hyp=hyp, compute_posterior=False)
+    assert np.isfinite(small.nll_batch(hyp, compute_grad=True)[0]).all()
+
+
+def test_the_product_library_does_not_know_the_rejected_schedules():
+    from gpyreg_amd import _lib
+
+    if _lib.is_experiments_build():
+        pytest.skip("the experiments build is loaded")
+    ctx = _lib.context(0)
+    assert ctx.get_option("experiments") == 0
+    for name in ("dag", "indep", "rect_min", "rl_panel", "dag_timeout_ms"):
+        with pytest.raises(RuntimeError) as e:
+            ctx.set_option(name, 1)
+        assert "unknown option" in str(e.value)
