@@ -5,6 +5,7 @@ import time
 import numpy as np
 import bench
 from gpyreg_amd import _lib
+_lib.context().set_option("small_timing", 1)  # (below N_pad = 2048 the timing events are recorded on request only)
 
 for N, S in [(200, 1024), (500, 1024), (1000, 1024), (2000, 256)]:
     bench.CONFIGS[2] = dict(bench.CONFIGS[2], N=N)

@@ -5,6 +5,7 @@ import os, sys, time
 import numpy as np
 import bench
 from gpyreg_amd import _lib
+_lib.context().set_option("small_timing", 1)  # (below N_pad = 2048 the timing events are recorded on request only)
 
 N, S = int(sys.argv[1]), int(sys.argv[2])
 grad = len(sys.argv) > 3 and sys.argv[3] == "grad"
